@@ -1,0 +1,879 @@
+// bchmc.hip -- host side of libbarcode_hip.so: the C ABI of include/bchmc.h on top of the kernels in
+// kernels.hpp and rocFFT R2C/C2R plans, all on one hipStream per handle.  gfx950 only.
+//
+// Trajectory layout: q and p live in Fourier space for the whole trajectory, so one
+// leapfrog step costs 3 C2R (displacements) + 3 R2C (V components) instead of the reference's 12 FFTs
+// (SURVEY.md 2.1 "FFT count per leapfrog step").
+#include "../../include/bchmc.h"
+#include "kernels.hpp"
+
+#include <rocfft/rocfft.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+using namespace bchmc;
+
+namespace {
+
+std::mutex g_rocfft_mu;
+int g_rocfft_users = 0;
+
+struct ProfRec {
+  int cls;
+  hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct bchmc_handle {
+  bchmc_config c{};
+  Geo g{};
+  int mass_fs = 0, mass_rs = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+
+  // rocFFT
+  rocfft_plan r2c1 = nullptr, c2r1 = nullptr, r2c3 = nullptr, c2r3 = nullptr;
+  rocfft_execution_info info = nullptr;
+  void *work = nullptr;
+  size_t work_bytes = 0;
+
+  // inputs (N doubles each) + derived half-layout multipliers
+  double *in_arr[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  bool have[6] = {false, false, false, false, false, false};
+  double *wS = nullptr, *wM = nullptr;  // normFS / signal_PS, normFS / mass_f on the half-complex layout
+
+  // state and scratch
+  double2 *qk = nullptr, *pk = nullptr, *gk = nullptr;  // Nh each
+  double2 *Ck = nullptr;                                // 3 Nh: Psi^ / V^
+  double2 *tC = nullptr;                                // Nh scratch
+  double *psi = nullptr;                                // 3 N: displacement components
+  double *V = nullptr;                                  // 3 N: V components
+  double *rho = nullptr, *plike = nullptr;              // N each
+  double *ioq = nullptr, *iop = nullptr;                // N each: staging / scratch
+  double *gprior = nullptr, *glike = nullptr;           // N each, lazily allocated by bchmc_gradient
+  double *rho_part = nullptr, *partA = nullptr;         // kRedBlocks doubles each
+  double *guard = nullptr;                              // guard slots, one per step
+  size_t guard_cap = 0;
+  int *stop = nullptr;
+  unsigned long long *steps_done = nullptr;
+  double *h_part = nullptr;                             // pinned host staging for partials
+  int4 *hull = nullptr;
+  int hull_n = 0;
+  int reach = 0;
+  bool have_eval = false;  // rho / psi hold a forward evaluation
+  int last_rsd = 0;
+
+  // profiling
+  bool prof_on = false;
+  std::vector<ProfRec> prof_recs;
+  std::vector<hipEvent_t> ev_pool;
+  double prof_ms[BCHMC_K_COUNT] = {0};
+  uint64_t prof_n[BCHMC_K_COUNT] = {0};
+
+  int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    err = buf;
+    return code;
+  }
+};
+
+#define HIPCHK(expr)                                                                          \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess) return h->fail(BCHMC_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+#define FFTCHK(expr)                                                                    \
+  do {                                                                                  \
+    rocfft_status s_ = (expr);                                                          \
+    if (s_ != rocfft_status_success) return h->fail(BCHMC_ERR_ROCFFT, "%s: status %d", #expr, (int)s_); \
+  } while (0)
+#define CHK(expr)           \
+  do {                      \
+    int rc_ = (expr);       \
+    if (rc_) return rc_;    \
+  } while (0)
+
+namespace {
+
+template <typename T>
+int dev_alloc(bchmc_handle *h, T **p, size_t count) {
+  hipError_t e = hipMalloc((void **)p, count * sizeof(T));
+  if (e != hipSuccess) return h->fail(BCHMC_ERR_NOMEM, "hipMalloc(%zu bytes): %s", count * sizeof(T), hipGetErrorString(e));
+  return BCHMC_OK;
+}
+
+inline int nblk_stride(long long n) { return (int)std::min<long long>((n + 255) / 256, 2048); }
+inline int nblk_full(long long n) { return (int)((n + 255) / 256); }
+
+// ---- profiling ------------------------------------------------------------------------------------
+struct ProfScope {
+  bchmc_handle *h;
+  int idx = -1;
+  ProfScope(bchmc_handle *h_, int cls) : h(h_) {
+    if (!h->prof_on) return;
+    ProfRec r;
+    r.cls = cls;
+    for (hipEvent_t *e : {&r.a, &r.b}) {
+      if (!h->ev_pool.empty()) {
+        *e = h->ev_pool.back();
+        h->ev_pool.pop_back();
+      } else {
+        (void)hipEventCreate(e);
+      }
+    }
+    (void)hipEventRecord(r.a, h->stream);
+    h->prof_recs.push_back(r);
+    idx = (int)h->prof_recs.size() - 1;
+  }
+  ~ProfScope() {
+    if (idx >= 0) (void)hipEventRecord(h->prof_recs[idx].b, h->stream);
+  }
+};
+
+void prof_collect(bchmc_handle *h) {
+  for (auto &r : h->prof_recs) {
+    float ms = 0.f;
+    (void)hipEventSynchronize(r.b);
+    (void)hipEventElapsedTime(&ms, r.a, r.b);
+    h->prof_ms[r.cls] += ms;
+    h->prof_n[r.cls] += 1;
+    h->ev_pool.push_back(r.a);
+    h->ev_pool.push_back(r.b);
+  }
+  h->prof_recs.clear();
+}
+
+// ---- FFT wrappers (unnormalised both ways; callers fold 1/N into the preceding k-space kernel) ------
+int fft_exec(bchmc_handle *h, rocfft_plan plan, void *in, void *out, int cls) {
+  ProfScope ps(h, cls);
+  void *ib[1] = {in}, *ob[1] = {out};
+  FFTCHK(rocfft_execute(plan, ib, ob, h->info));
+  return BCHMC_OK;
+}
+
+// ---- parameter packs --------------------------------------------------------------------------------
+double E_Hubble_a(double a, double OM, double OL) {  // cosmo.cc:26-31
+  const double OK = 1. - OM - OL;
+  return std::sqrt(OM / (a * a * a) + OK / (a * a) + OL);
+}
+double fgrow1(double a, double OM, double OL) {  // cosmo.cc:182-217, term 1
+  const double E = E_Hubble_a(a, OM, OL);
+  const double Omega = OM / ((E * E) * (a * a * a));
+  return std::pow(Omega, 5. / 9.);
+}
+double c_pecvel1(double a, double OM, double OL) {  // cosmo.cc:220-235
+  return fgrow1(a, OM, OL) * 100. * E_Hubble_a(a, OM, OL) * a;
+}
+
+PosPar make_pos(const bchmc_handle *h, int rsd) {
+  PosPar pp;
+  pp.d = h->g.d;
+  pp.L = h->g.L;
+  pp.rsd = rsd;
+  pp.periodic = 1;  // disp_part.cc:28 hard-codes periodic = true
+  const double a = h->c.ascale, OM = h->c.OM, OL = h->c.OL;
+  pp.cpecvel = c_pecvel1(a, OM, OL);
+  const double Hub = 100. * std::sqrt(OM / a / a / a + OL + (1. - OM - OL) / a / a);  // rsd.cc:26-27
+  pp.v_norm = 1. / Hub / a;
+  return pp;
+}
+
+SphPar make_sph(const bchmc_handle *h) {
+  SphPar sp;
+  sp.h = h->c.particle_kernel_h;
+  sp.w_norm = 1. / M_PI / (sp.h * sp.h * sp.h);
+  sp.r2_lim = 4. * sp.h * sp.h * (1. + 1e-12);
+  sp.min1 = h->c.min1;
+  sp.min2 = h->c.min2;
+  sp.min3 = h->c.min3;
+  sp.reach = h->reach;
+  return sp;
+}
+
+LikePar make_like(const bchmc_handle *h) {
+  LikePar lp;
+  lp.rho_c = h->c.rho_c;
+  lp.biasP = h->c.biasP;
+  lp.biasE = h->c.biasE;
+  lp.delta_min = h->c.delta_min;
+  lp.likelihood = h->c.likelihood;
+  lp.bias_is_identity = (h->c.biasE == 1.0);
+  return lp;
+}
+
+HullPar make_hull(const bchmc_handle *h) {
+  HullPar hp;
+  const double hh = h->c.particle_kernel_h;
+  hp.cols = h->hull;
+  hp.ncol = h->hull_n;
+  hp.h_inv = 1. / hh;
+  hp.d_h = h->g.d * hp.h_inv;
+  hp.norm = 1. / (M_PI * (hh * hh) * (hh * hh));
+  hp.normalize = h->c.rho_c * h->g.L * h->g.L * h->g.L / (double)h->g.N;
+  hp.f1 = fgrow1(h->c.ascale, h->c.OM, h->c.OL);
+  return hp;
+}
+
+// SPH stencil -> (i, j) column hull: SPH_kernel_3D_cells (SPH_kernel.cpp:62-102) + hull_1 (110-139)
+void build_hull(double hh, double d, std::vector<int4> &cols, int &reach_out) {
+  const double reach = hh * 2;
+  const int r = (int)(reach / d) + 1;
+  reach_out = r;
+  const double reach_sq = reach * reach;
+  cols.clear();
+  for (int i1 = -r; i1 <= r; ++i1)
+    for (int i2 = -r; i2 <= r; ++i2)
+      for (int i3 = -r; i3 <= r; ++i3) {
+        const double dx = (std::fabs((double)i1) - 0.5) * d, dy = (std::fabs((double)i2) - 0.5) * d,
+                     dz = (std::fabs((double)i3) - 0.5) * d;
+        if (dx * dx + dy * dy + dz * dz <= reach_sq) {
+          bool found = false;
+          for (auto &c : cols)
+            if (c.x == i1 && c.y == i2) {
+              c.z = std::min(c.z, i3);
+              c.w = std::max(c.w, i3);
+              found = true;
+              break;
+            }
+          if (!found) cols.push_back(make_int4(i1, i2, i3, i3));
+        }
+      }
+}
+
+int need_input(bchmc_handle *h, int f, const char *name) {
+  if (!h->have[f]) return h->fail(BCHMC_ERR_STATE, "input array %s was never uploaded", name);
+  return BCHMC_OK;
+}
+
+int check_inputs(bchmc_handle *h, bool force) {
+  CHK(need_input(h, BCHMC_F_SIGNAL_PS, "signal_PS"));
+  if (h->mass_fs) CHK(need_input(h, BCHMC_F_MASS_F, "mass_f"));
+  if (h->mass_rs) CHK(need_input(h, BCHMC_F_MASS_R, "mass_r"));
+  CHK(need_input(h, BCHMC_F_NOBS, "nobs"));
+  CHK(need_input(h, BCHMC_F_WINDOW, "window"));
+  if (h->c.likelihood != 0) CHK(need_input(h, BCHMC_F_NOISE, "noise"));
+  (void)force;
+  return BCHMC_OK;
+}
+
+// Sum kRedBlocks device partials on the host (synchronises the stream).
+int host_sum(bchmc_handle *h, const double *d_part, double *out) {
+  HIPCHK(hipMemcpyAsync(h->h_part, d_part, kRedBlocks * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  double s = 0.;
+  for (int i = 0; i < kRedBlocks; i++) s += h->h_part[i];
+  *out = s;
+  return BCHMC_OK;
+}
+
+// ---- building blocks of one force / energy evaluation ---------------------------------------------------
+
+// Psi^ from the current q^ (no kick, no drift)
+int launch_za(bchmc_handle *h, double dq_factor) {
+  ProfScope ps(h, BCHMC_K_KSPACE_DRIFT_ZA);
+  StepCtl ctl{h->stop, h->steps_done, nullptr, 0., 0};
+  const double c_za = -h->c.D1 * dq_factor / (double)h->g.N;
+  k_kick_drift_za<false><<<nblk_stride(h->g.Nh), 256, 0, h->stream>>>(h->g, h->qk, h->pk, h->gk, nullptr, nullptr,
+                                                                       h->Ck, 0., 0., c_za, ctl);
+  HIPCHK(hipGetLastError());
+  return BCHMC_OK;
+}
+
+// C2R of the three displacement components, mass assignment, sum of rho.  Lag2Eul.cc:90-131 / 363-423.
+int forward_rest(bchmc_handle *h, int rsd) {
+  if (rsd && !h->c.planepar) return h->fail(BCHMC_ERR_RSD_NOT_PLANEPAR, "non-plane-parallel RSD is not implemented");
+  CHK(fft_exec(h, h->c2r3, h->Ck, h->psi, BCHMC_K_FFT_C2R));
+  {
+    ProfScope ps(h, BCHMC_K_SCATTER);
+    HIPCHK(hipMemsetAsync(h->rho, 0, h->g.N * sizeof(double), h->stream));
+    if (h->c.mk == 3) {
+      k_scatter_sph<<<nblk_full(h->g.N), 256, 0, h->stream>>>(h->g, make_pos(h, rsd), make_sph(h), h->psi, h->rho);
+    } else {
+      return h->fail(BCHMC_ERR_UNSUPPORTED, "masskernel %d not built yet (only 3 = SPH)", h->c.mk);
+    }
+    HIPCHK(hipGetLastError());
+  }
+  {
+    ProfScope ps(h, BCHMC_K_MEAN_PARTIAL);
+    k_sum<<<kRedBlocks, 256, 0, h->stream>>>(h->rho, h->g.N, h->rho_part);
+    HIPCHK(hipGetLastError());
+  }
+  h->have_eval = true;
+  h->last_rsd = rsd;
+  return BCHMC_OK;
+}
+
+// After forward_rest: leaves the k-space likelihood source in Ck and returns the assemble mode.
+int like_force(bchmc_handle *h, int *like_mode) {
+  if (h->c.calc_h == 2 || h->c.calc_h == 3) {
+    if (h->c.mk != 3)
+      return h->fail(BCHMC_ERR_MK_NOT_SPH, "Must use SPH mass kernel (masskernel = 3) with calc_h = 2 or 3");
+    if (h->c.calc_h == 3) return h->fail(BCHMC_ERR_UNSUPPORTED, "calc_h = 3 (Fourier/TSC) not built yet");
+  } else if (h->c.calc_h != 1) {
+    return h->fail(BCHMC_ERR_UNSUPPORTED, "calc_h = %d not supported (use 1, 2 or 3)", h->c.calc_h);
+  }
+  {
+    ProfScope ps(h, BCHMC_K_MEAN_PARTIAL);
+    k_partial_like<<<nblk_stride(h->g.N), 256, 0, h->stream>>>(h->g, make_like(h), h->rho, h->rho_part,
+                                                               h->in_arr[BCHMC_F_NOBS], h->in_arr[BCHMC_F_NOISE],
+                                                               h->in_arr[BCHMC_F_WINDOW], h->plike);
+    HIPCHK(hipGetLastError());
+  }
+  if (h->c.calc_h == 1) {
+    CHK(fft_exec(h, h->r2c1, h->plike, h->Ck, BCHMC_K_FFT_R2C));
+    *like_mode = 1;
+    return BCHMC_OK;
+  }
+  {
+    ProfScope ps(h, BCHMC_K_GATHER);
+    HullPar hp = make_hull(h);
+    k_gather_sph<<<nblk_full(h->g.N), 256, hp.ncol * sizeof(int4), h->stream>>>(h->g, make_pos(h, h->last_rsd), hp,
+                                                                                h->psi, h->plike, h->V);
+    HIPCHK(hipGetLastError());
+  }
+  CHK(fft_exec(h, h->r2c3, h->V, h->Ck, BCHMC_K_FFT_R2C));
+  *like_mode = 0;
+  return BCHMC_OK;
+}
+
+// GRF likelihood force (gaussian_random_field.cpp:25-37): needs q in real space.
+int grf_force(bchmc_handle *h) {
+  {
+    ProfScope ps(h, BCHMC_K_OTHER);
+    k_scale_c<<<nblk_stride(h->g.Nh), 256, 0, h->stream>>>(h->g.Nh, h->qk, h->tC, 1. / (double)h->g.N);
+    HIPCHK(hipGetLastError());
+  }
+  CHK(fft_exec(h, h->c2r1, h->tC, h->plike, BCHMC_K_FFT_C2R));
+  {
+    ProfScope ps(h, BCHMC_K_OTHER);
+    k_grf_grad<<<nblk_stride(h->g.N), 256, 0, h->stream>>>(h->g.N, h->plike, h->in_arr[BCHMC_F_NOBS],
+                                                           h->in_arr[BCHMC_F_NOISE], h->in_arr[BCHMC_F_WINDOW], h->rho);
+    HIPCHK(hipGetLastError());
+  }
+  CHK(fft_exec(h, h->r2c1, h->rho, h->Ck, BCHMC_K_FFT_R2C));
+  h->have_eval = false;
+  return BCHMC_OK;
+}
+
+// Likelihood part of gradient_psi from the current q^: fills Ck, returns (like_mode, b).
+// pre_za: Psi^ is already in Ck (the fused kick+drift+ZA kernel ran).
+int force_sources(bchmc_handle *h, bool pre_za, int *like_mode, double *b) {
+  if (h->c.likelihood == 3) {
+    CHK(grf_force(h));
+    *like_mode = 1;
+    *b = h->c.grad_psi_likeli_factor;
+    return BCHMC_OK;
+  }
+  if (!pre_za) CHK(launch_za(h, h->c.deltaQ_factor));
+  CHK(forward_rest(h, h->c.rsd_model));
+  CHK(like_force(h, like_mode));
+  double norm = -1.;  // zeldovich_norm, HMC_models.cc:458-461
+  norm *= h->c.deltaQ_factor;
+  if (h->c.correct_delta) norm *= h->c.D1;
+  *b = h->c.grad_psi_likeli_factor * norm;
+  return BCHMC_OK;
+}
+
+template <bool KICK>
+int launch_assemble(bchmc_handle *h, double a, double b, int like_mode, double c_kick, double *guard_slot,
+                    double2 *gk_out) {
+  ProfScope ps(h, BCHMC_K_KSPACE_FORCE_KICK);
+  k_assemble<KICK><<<nblk_stride(h->g.Nh), 256, 0, h->stream>>>(h->g, h->Ck, h->qk, h->wS, gk_out, h->pk, a, b,
+                                                                like_mode, c_kick, guard_slot, h->stop);
+  HIPCHK(hipGetLastError());
+  return BCHMC_OK;
+}
+
+int r2c_state(bchmc_handle *h, const double *d_real, double *staging, double2 *out) {
+  // rocFFT may use the input as scratch; transform from our own staging copy.
+  if (d_real != staging)
+    HIPCHK(hipMemcpyAsync(staging, d_real, h->g.N * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  return fft_exec(h, h->r2c1, staging, out, BCHMC_K_FFT_R2C);
+}
+
+int c2r_state(bchmc_handle *h, const double2 *xk, double *d_out) {
+  {
+    ProfScope ps(h, BCHMC_K_OTHER);
+    k_scale_c<<<nblk_stride(h->g.Nh), 256, 0, h->stream>>>(h->g.Nh, xk, h->tC, 1. / (double)h->g.N);
+    HIPCHK(hipGetLastError());
+  }
+  return fft_exec(h, h->c2r1, h->tC, d_out, BCHMC_K_FFT_C2R);
+}
+
+// extra = R2C[ C2R[p^]/N / mass_r ]  (real-space mass term of the drift, HMC.cc:317-327)
+int mass_rs_term(bchmc_handle *h) {
+  CHK(c2r_state(h, h->pk, h->iop));
+  {
+    ProfScope ps(h, BCHMC_K_OTHER);
+    k_div_mass_r<<<nblk_stride(h->g.N), 256, 0, h->stream>>>(h->g.N, h->iop, h->in_arr[BCHMC_F_MASS_R], h->iop);
+    HIPCHK(hipGetLastError());
+  }
+  return fft_exec(h, h->r2c1, h->iop, h->tC, BCHMC_K_FFT_R2C);
+}
+
+int leapfrog_core(bchmc_handle *h, const double *d_q0, const double *d_p0, double *d_q1, double *d_p1, double eps,
+                  uint64_t neps) {
+  CHK(check_inputs(h, true));
+  if (eps > 2.) eps = 2.;  // HMC.cc:263-264
+  if (neps + 1 > h->guard_cap) {
+    if (h->guard) (void)hipFree(h->guard);
+    h->guard = nullptr;
+    h->guard_cap = std::max<size_t>(64, 2 * (neps + 1));
+    CHK(dev_alloc(h, &h->guard, h->guard_cap));
+  }
+  HIPCHK(hipMemsetAsync(h->guard, 0, (neps + 1) * sizeof(double), h->stream));
+  k_init_ctl<<<1, 1, 0, h->stream>>>(h->stop, h->steps_done, (unsigned long long)neps);
+  HIPCHK(hipGetLastError());
+
+  CHK(r2c_state(h, d_q0, h->ioq, h->qk));
+  CHK(r2c_state(h, d_p0, h->iop, h->pk));
+
+  const double a = h->c.grad_psi_prior_factor;
+  int like_mode = 2;
+  double b = 0.;
+  // 0) gradient at t = 0 (HMC.cc:279-280)
+  CHK(force_sources(h, false, &like_mode, &b));
+  CHK(launch_assemble<false>(h, a, b, like_mode, 0., nullptr, h->gk));
+
+  const bool fused_za = (h->c.likelihood != 3);
+  for (uint64_t s = 0; s < neps; s++) {
+    StepCtl ctl{h->stop, h->steps_done, s > 0 ? h->guard + (s - 1) : nullptr, 1e50 * (double)h->g.N, s};
+    const double c_za = -h->c.D1 * h->c.deltaQ_factor / (double)h->g.N;
+    if (!h->mass_rs) {
+      ProfScope ps(h, BCHMC_K_KSPACE_DRIFT_ZA);
+      k_kick_drift_za<true><<<nblk_stride(h->g.Nh), 256, 0, h->stream>>>(
+          h->g, h->qk, h->pk, h->gk, h->mass_fs ? h->wM : nullptr, nullptr, h->Ck, 0.5 * eps, eps, c_za, ctl);
+      HIPCHK(hipGetLastError());
+    } else {
+      // kick first (needs p in real space for the mass_r term), then drift with the extra term
+      {
+        ProfScope ps(h, BCHMC_K_KSPACE_DRIFT_ZA);
+        k_kick_drift_za<true><<<nblk_stride(h->g.Nh), 256, 0, h->stream>>>(h->g, h->qk, h->pk, h->gk, nullptr, nullptr,
+                                                                           h->Ck, 0.5 * eps, 0., c_za, ctl);
+        HIPCHK(hipGetLastError());
+      }
+      CHK(mass_rs_term(h));
+      StepCtl ctl2{h->stop, h->steps_done, nullptr, 0., s};
+      ProfScope ps(h, BCHMC_K_KSPACE_DRIFT_ZA);
+      k_kick_drift_za<true><<<nblk_stride(h->g.Nh), 256, 0, h->stream>>>(
+          h->g, h->qk, h->pk, h->gk, h->mass_fs ? h->wM : nullptr, h->tC, h->Ck, 0., eps, c_za, ctl2);
+      HIPCHK(hipGetLastError());
+    }
+    CHK(force_sources(h, fused_za, &like_mode, &b));
+    CHK(launch_assemble<true>(h, a, b, like_mode, 0.5 * eps, h->guard + s, h->gk));
+  }
+  CHK(c2r_state(h, h->qk, d_q1));
+  CHK(c2r_state(h, h->pk, d_p1));
+  return BCHMC_OK;
+}
+
+int energies_core(bchmc_handle *h, const double *d_q, const double *d_p, double out[3]) {
+  CHK(check_inputs(h, false));
+  const double N = (double)h->g.N;
+  CHK(r2c_state(h, d_q, h->ioq, h->qk));
+  CHK(r2c_state(h, d_p, h->iop, h->pk));
+  double kin = 0., v;
+  if (h->mass_fs) {
+    ProfScope ps(h, BCHMC_K_OTHER);
+    k_parseval<<<kRedBlocks, 256, 0, h->stream>>>(h->g, h->pk, h->wM, h->partA);
+    HIPCHK(hipGetLastError());
+  }
+  if (h->mass_fs) {
+    CHK(host_sum(h, h->partA, &v));
+    kin += v / (2. * N);
+  }
+  if (h->mass_rs) {
+    k_kin_rs<<<kRedBlocks, 256, 0, h->stream>>>(h->g.N, d_p, h->in_arr[BCHMC_F_MASS_R], h->partA);
+    HIPCHK(hipGetLastError());
+    CHK(host_sum(h, h->partA, &v));
+    kin += v;
+  }
+  k_parseval<<<kRedBlocks, 256, 0, h->stream>>>(h->g, h->qk, h->wS, h->partA);
+  HIPCHK(hipGetLastError());
+  CHK(host_sum(h, h->partA, &v));
+  const double prior = v / (2. * N);
+  double like = 0.;
+  if (h->c.likelihood == 3) {
+    k_grf_loglike<<<kRedBlocks, 256, 0, h->stream>>>(h->g.N, d_q, h->in_arr[BCHMC_F_NOBS], h->in_arr[BCHMC_F_NOISE],
+                                                     h->in_arr[BCHMC_F_WINDOW], h->partA);
+    HIPCHK(hipGetLastError());
+    CHK(host_sum(h, h->partA, &like));
+  } else {
+    // gaussian log_like applies deltaQ_factor and honours rsd_model (gaussian_independent.cpp:57-76);
+    // poissonian / log-normal log_like do neither (poissonian.cpp:54-56, lognormal_independent.cpp:105-107)
+    const bool gauss = (h->c.likelihood == 1);
+    CHK(launch_za(h, gauss ? h->c.deltaQ_factor : 1.));
+    CHK(forward_rest(h, gauss ? h->c.rsd_model : 0));
+    k_loglike<<<kRedBlocks, 256, 0, h->stream>>>(h->g, make_like(h), h->rho, h->rho_part, h->in_arr[BCHMC_F_NOBS],
+                                                 h->in_arr[BCHMC_F_NOISE], h->in_arr[BCHMC_F_WINDOW], h->partA);
+    HIPCHK(hipGetLastError());
+    CHK(host_sum(h, h->partA, &like));
+  }
+  out[0] = kin;
+  out[1] = prior;
+  out[2] = like;
+  return BCHMC_OK;
+}
+
+int validate_config(const bchmc_config *c, std::string &why) {
+  char buf[256];
+  if (c->abi_version != BCHMC_ABI_VERSION) {
+    snprintf(buf, sizeof buf, "abi_version %u != %u", c->abi_version, BCHMC_ABI_VERSION);
+    why = buf;
+    return BCHMC_ERR_ARG;
+  }
+  if (c->Nx < 4 || !(c->L > 0) || !(c->particle_kernel_h > 0)) {
+    why = "Nx >= 4, L > 0 and particle_kernel_h > 0 are required";
+    return BCHMC_ERR_ARG;
+  }
+  if (c->precision != 0) {
+    why = "only precision 0 (fp64 fields) is built";
+    return BCHMC_ERR_UNSUPPORTED;
+  }
+  if (c->likelihood < 0 || c->likelihood > 3) {
+    why = "likelihood must be 0..3";
+    return BCHMC_ERR_ARG;
+  }
+  if (!c->rsd_model && c->sfmodel != 1 && c->likelihood != 3) {
+    why = "sfmodel != 1 (ALPT forward model) is not built; Zel'dovich only";
+    return BCHMC_ERR_UNSUPPORTED;
+  }
+  if (c->particle_kernel_h > c->L / 4) {
+    why = "particle_kernel_h of more than Nx/4 cells (init_par.cc:373-375)";
+    return BCHMC_ERR_ARG;
+  }
+  return BCHMC_OK;
+}
+
+}  // namespace
+
+// ======================================================================================================
+// C ABI
+// ======================================================================================================
+extern "C" {
+
+const char *bchmc_strerror(int code) {
+  switch (code) {
+    case BCHMC_OK: return "ok";
+    case BCHMC_ERR_ARG: return "invalid argument";
+    case BCHMC_ERR_MK_NOT_SPH: return "Must use SPH mass kernel (masskernel = 3) when using calc_h = 2 or 3";
+    case BCHMC_ERR_RSD_NOT_PLANEPAR: return "Non-plane-parallel RSD model is not implemented; use planepar = true";
+    case BCHMC_ERR_MASS_TYPE: return "mass_type is not a valid value";
+    case BCHMC_ERR_UNSUPPORTED: return "configuration not supported by this build";
+    case BCHMC_ERR_HIP: return "HIP runtime error";
+    case BCHMC_ERR_ROCFFT: return "rocFFT error";
+    case BCHMC_ERR_NOMEM: return "out of device memory";
+    case BCHMC_ERR_STATE: return "engine state error (missing input?)";
+  }
+  return "unknown error";
+}
+
+const char *bchmc_last_error(const bchmc_handle *h) { return h ? h->err.c_str() : ""; }
+
+const char *bchmc_kernel_name(int cls) {
+  static const char *names[BCHMC_K_COUNT] = {"rocfft_c2r", "rocfft_r2c",        "k_kick_drift_za", "k_scatter_sph",
+                                            "k_sum+k_partial_like", "k_gather_sph", "k_assemble",      "other"};
+  return (cls >= 0 && cls < BCHMC_K_COUNT) ? names[cls] : "?";
+}
+
+int bchmc_create(const bchmc_config *cfg, bchmc_handle **out) {
+  if (!cfg || !out) return BCHMC_ERR_ARG;
+  *out = nullptr;
+  bchmc_handle *h = new bchmc_handle();
+  auto bail = [&](int rc) {
+    // keep the handle alive so the caller can read bchmc_last_error; it is freed by bchmc_destroy
+    *out = h;
+    return rc;
+  };
+  int rc = validate_config(cfg, h->err);
+  if (rc) return bail(rc);
+  h->c = *cfg;
+  switch (cfg->mass_type) {  // struct_hamil.h:272-313
+    case 0: case 6: case 60: h->mass_rs = 1; h->mass_fs = 0; break;
+    case 1: case 2: case 3: case 4: h->mass_rs = 0; h->mass_fs = 1; break;
+    case 5: h->mass_rs = 1; h->mass_fs = 1; break;
+    default: return bail(h->fail(BCHMC_ERR_MASS_TYPE, "mass_type %d is not a valid value!", cfg->mass_type));
+  }
+  Geo &g = h->g;
+  g.n = (int)cfg->Nx;
+  g.nh = g.n / 2 + 1;
+  g.N = (long long)g.n * g.n * g.n;
+  g.Nh = (long long)g.n * g.n * g.nh;
+  g.L = cfg->L;
+  g.d = cfg->L / (double)cfg->Nx;
+  g.kfac = 2. * M_PI / cfg->L;
+
+  auto run = [&]() -> int {
+    HIPCHK(hipSetDevice(cfg->device));
+    HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    {
+      std::lock_guard<std::mutex> lk(g_rocfft_mu);
+      if (g_rocfft_users++ == 0) FFTCHK(rocfft_setup());
+    }
+    const size_t len[3] = {(size_t)g.n, (size_t)g.n, (size_t)g.n};  // fastest first; cubic
+    FFTCHK(rocfft_plan_create(&h->r2c1, rocfft_placement_notinplace, rocfft_transform_type_real_forward,
+                              rocfft_precision_double, 3, len, 1, nullptr));
+    FFTCHK(rocfft_plan_create(&h->c2r1, rocfft_placement_notinplace, rocfft_transform_type_real_inverse,
+                              rocfft_precision_double, 3, len, 1, nullptr));
+    FFTCHK(rocfft_plan_create(&h->r2c3, rocfft_placement_notinplace, rocfft_transform_type_real_forward,
+                              rocfft_precision_double, 3, len, 3, nullptr));
+    FFTCHK(rocfft_plan_create(&h->c2r3, rocfft_placement_notinplace, rocfft_transform_type_real_inverse,
+                              rocfft_precision_double, 3, len, 3, nullptr));
+    for (rocfft_plan p : {h->r2c1, h->c2r1, h->r2c3, h->c2r3}) {
+      size_t wb = 0;
+      FFTCHK(rocfft_plan_get_work_buffer_size(p, &wb));
+      h->work_bytes = std::max(h->work_bytes, wb);
+    }
+    FFTCHK(rocfft_execution_info_create(&h->info));
+    FFTCHK(rocfft_execution_info_set_stream(h->info, h->stream));
+    if (h->work_bytes) {
+      HIPCHK(hipMalloc(&h->work, h->work_bytes));
+      FFTCHK(rocfft_execution_info_set_work_buffer(h->info, h->work, h->work_bytes));
+    }
+    const size_t N = (size_t)g.N, Nh = (size_t)g.Nh;
+    for (int f = 0; f < 6; f++) CHK(dev_alloc(h, &h->in_arr[f], N));
+    CHK(dev_alloc(h, &h->wS, Nh));
+    CHK(dev_alloc(h, &h->wM, Nh));
+    CHK(dev_alloc(h, &h->qk, Nh));
+    CHK(dev_alloc(h, &h->pk, Nh));
+    CHK(dev_alloc(h, &h->gk, Nh));
+    CHK(dev_alloc(h, &h->Ck, 3 * Nh));
+    CHK(dev_alloc(h, &h->tC, Nh));
+    CHK(dev_alloc(h, &h->psi, 3 * N));
+    CHK(dev_alloc(h, &h->V, 3 * N));
+    CHK(dev_alloc(h, &h->rho, N));
+    CHK(dev_alloc(h, &h->plike, N));
+    CHK(dev_alloc(h, &h->ioq, N));
+    CHK(dev_alloc(h, &h->iop, N));
+    CHK(dev_alloc(h, &h->rho_part, (size_t)kRedBlocks));
+    CHK(dev_alloc(h, &h->partA, (size_t)kRedBlocks));
+    CHK(dev_alloc(h, &h->stop, (size_t)1));
+    CHK(dev_alloc(h, &h->steps_done, (size_t)1));
+    HIPCHK(hipMemsetAsync(h->stop, 0, sizeof(int), h->stream));
+    HIPCHK(hipHostMalloc((void **)&h->h_part, kRedBlocks * sizeof(double)));
+    // noise defaults to 1 so that likelihoods that never read it need no upload
+    std::vector<int4> cols;
+    build_hull(cfg->particle_kernel_h, g.d, cols, h->reach);
+    h->hull_n = (int)cols.size();
+    CHK(dev_alloc(h, &h->hull, cols.size()));
+    HIPCHK(hipMemcpy(h->hull, cols.data(), cols.size() * sizeof(int4), hipMemcpyHostToDevice));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return BCHMC_OK;
+  };
+  rc = run();
+  *out = h;
+  return rc;
+}
+
+void bchmc_destroy(bchmc_handle *h) {
+  if (!h) return;
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  prof_collect(h);
+  for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
+  for (rocfft_plan p : {h->r2c1, h->c2r1, h->r2c3, h->c2r3})
+    if (p) rocfft_plan_destroy(p);
+  if (h->info) rocfft_execution_info_destroy(h->info);
+  void *ptrs[] = {h->work, h->wS,  h->wM,  h->qk,  h->pk,     h->gk,    h->Ck,       h->tC,    h->psi,  h->V,
+                  h->rho,  h->plike, h->ioq, h->iop, h->gprior, h->glike, h->rho_part, h->partA, h->guard, h->stop,
+                  h->steps_done, h->hull};
+  for (void *p : ptrs)
+    if (p) (void)hipFree(p);
+  for (int f = 0; f < 6; f++)
+    if (h->in_arr[f]) (void)hipFree(h->in_arr[f]);
+  if (h->h_part) (void)hipHostFree(h->h_part);
+  if (h->stream) {
+    (void)hipStreamDestroy(h->stream);
+    std::lock_guard<std::mutex> lk(g_rocfft_mu);
+    if (--g_rocfft_users == 0) rocfft_cleanup();
+  }
+  delete h;
+}
+
+int bchmc_upload(bchmc_handle *h, bchmc_field field, const double *host, size_t n) {
+  if (!h || !host) return BCHMC_ERR_ARG;
+  if ((int)field < 0 || (int)field > BCHMC_F_WINDOW) return h->fail(BCHMC_ERR_ARG, "field %d is not an input", (int)field);
+  if (n != (size_t)h->g.N) return h->fail(BCHMC_ERR_ARG, "upload size %zu != N = %lld", n, h->g.N);
+  HIPCHK(hipMemcpyAsync(h->in_arr[field], host, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  const double normFS = h->g.L * h->g.L * h->g.L / (double)h->g.N;  // FOURIER_DEF_2, HMC_help.cc:25-27
+  if (field == BCHMC_F_SIGNAL_PS || field == BCHMC_F_MASS_F) {
+    double *w = field == BCHMC_F_SIGNAL_PS ? h->wS : h->wM;
+    k_prepare_mult<<<nblk_stride(h->g.Nh), 256, 0, h->stream>>>(h->g, h->in_arr[field], w, normFS);
+    HIPCHK(hipGetLastError());
+  }
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->have[field] = true;
+  return BCHMC_OK;
+}
+
+int bchmc_sync(bchmc_handle *h) {
+  if (!h) return BCHMC_ERR_ARG;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return BCHMC_OK;
+}
+
+void *bchmc_stream(bchmc_handle *h) { return h ? (void *)h->stream : nullptr; }
+
+int bchmc_leapfrog_device(bchmc_handle *h, const double *d_q0, const double *d_p0, double *d_q1, double *d_p1,
+                          double eps, uint64_t neps) {
+  if (!h || !d_q0 || !d_p0 || !d_q1 || !d_p1) return BCHMC_ERR_ARG;
+  return leapfrog_core(h, d_q0, d_p0, d_q1, d_p1, eps, neps);
+}
+
+int bchmc_steps_done(bchmc_handle *h, uint64_t *steps_done) {
+  if (!h || !steps_done) return BCHMC_ERR_ARG;
+  unsigned long long v = 0;
+  HIPCHK(hipMemcpyAsync(&v, h->steps_done, sizeof v, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  *steps_done = v;
+  return BCHMC_OK;
+}
+
+int bchmc_leapfrog(bchmc_handle *h, const double *q0, const double *p0, double *q1, double *p1, double eps,
+                   uint64_t neps, uint64_t *steps_done) {
+  if (!h || !q0 || !p0 || !q1 || !p1) return BCHMC_ERR_ARG;
+  const size_t bytes = h->g.N * sizeof(double);
+  HIPCHK(hipMemcpyAsync(h->ioq, q0, bytes, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->iop, p0, bytes, hipMemcpyHostToDevice, h->stream));
+  // results land in psi[0..N) / psi[N..2N) (free once the last force evaluation is done)
+  CHK(leapfrog_core(h, h->ioq, h->iop, h->V, h->V + h->g.N, eps, neps));
+  HIPCHK(hipMemcpyAsync(q1, h->V, bytes, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(p1, h->V + h->g.N, bytes, hipMemcpyDeviceToHost, h->stream));
+  uint64_t done = 0;
+  CHK(bchmc_steps_done(h, &done));
+  if (steps_done) *steps_done = done;
+  return BCHMC_OK;
+}
+
+int bchmc_energies_device(bchmc_handle *h, const double *d_q, const double *d_p, double out[3]) {
+  if (!h || !d_q || !d_p || !out) return BCHMC_ERR_ARG;
+  return energies_core(h, d_q, d_p, out);
+}
+
+int bchmc_energies(bchmc_handle *h, const double *q, const double *p, double out[3]) {
+  if (!h || !q || !p || !out) return BCHMC_ERR_ARG;
+  const size_t bytes = h->g.N * sizeof(double);
+  HIPCHK(hipMemcpyAsync(h->ioq, q, bytes, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->iop, p, bytes, hipMemcpyHostToDevice, h->stream));
+  return energies_core(h, h->ioq, h->iop, out);
+}
+
+int bchmc_delta_hamiltonian(bchmc_handle *h, const double *qi, const double *pi, const double *qf, const double *pf,
+                            double *dH, double terms[6]) {
+  if (!h || !dH || !terms) return BCHMC_ERR_ARG;
+  CHK(bchmc_energies(h, qi, pi, terms));
+  CHK(bchmc_energies(h, qf, pf, terms + 3));
+  const double Hami = terms[0] + (terms[1] + terms[2]);
+  const double Hamf = terms[3] + (terms[4] + terms[5]);
+  double d = Hamf - Hami;
+  if (h->c.div_dH_by_N) d /= (double)h->g.N;  // HMC.cc:234-237
+  *dH = d;
+  return BCHMC_OK;
+}
+
+int bchmc_forward(bchmc_handle *h, const double *q, int use_rsd) {
+  if (!h || !q) return BCHMC_ERR_ARG;
+  if (h->c.likelihood == 3 && h->c.sfmodel != 1 && !h->c.rsd_model)
+    return h->fail(BCHMC_ERR_UNSUPPORTED, "sfmodel != 1 forward model is not built");
+  HIPCHK(hipMemcpyAsync(h->ioq, q, h->g.N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  CHK(r2c_state(h, h->ioq, h->ioq, h->qk));
+  CHK(launch_za(h, 1.));
+  CHK(forward_rest(h, use_rsd < 0 ? h->c.rsd_model : (use_rsd ? 1 : 0)));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return BCHMC_OK;
+}
+
+int bchmc_gradient(bchmc_handle *h, const double *q, double *gout) {
+  if (!h || !q || !gout) return BCHMC_ERR_ARG;
+  CHK(check_inputs(h, true));
+  const size_t N = (size_t)h->g.N;
+  if (!h->gprior) {
+    CHK(dev_alloc(h, &h->gprior, N));
+    CHK(dev_alloc(h, &h->glike, N));
+  }
+  HIPCHK(hipMemcpyAsync(h->ioq, q, N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  CHK(r2c_state(h, h->ioq, h->ioq, h->qk));
+  int like_mode = 2;
+  double b = 0.;
+  CHK(force_sources(h, false, &like_mode, &b));
+  CHK(launch_assemble<false>(h, h->c.grad_psi_prior_factor, 0., 2, 0., nullptr, h->gk));
+  CHK(c2r_state(h, h->gk, h->gprior));
+  CHK(launch_assemble<false>(h, 0., b, like_mode, 0., nullptr, h->gk));
+  CHK(c2r_state(h, h->gk, h->glike));
+  k_add_r<<<nblk_stride(h->g.N), 256, 0, h->stream>>>(h->g.N, h->gprior, h->glike, h->iop);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(gout, h->iop, N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return BCHMC_OK;
+}
+
+int bchmc_fetch(bchmc_handle *h, bchmc_field field, double *host, size_t n) {
+  if (!h || !host) return BCHMC_ERR_ARG;
+  if (n != (size_t)h->g.N) return h->fail(BCHMC_ERR_ARG, "fetch size %zu != N = %lld", n, h->g.N);
+  const size_t N = (size_t)h->g.N;
+  const double *src = nullptr;
+  const bool needs_eval = (field >= BCHMC_F_DELTAX && field <= BCHMC_F_PSIZ);
+  if (needs_eval && !h->have_eval) return h->fail(BCHMC_ERR_STATE, "no forward evaluation to fetch from");
+  switch (field) {
+    case BCHMC_F_SIGNAL_PS: case BCHMC_F_MASS_F: case BCHMC_F_MASS_R:
+    case BCHMC_F_NOBS: case BCHMC_F_NOISE: case BCHMC_F_WINDOW:
+      src = h->in_arr[field];
+      break;
+    case BCHMC_F_DELTAX:
+      k_overdens<<<nblk_stride(h->g.N), 256, 0, h->stream>>>(h->g, h->rho, h->rho_part, h->ioq);
+      HIPCHK(hipGetLastError());
+      src = h->ioq;
+      break;
+    case BCHMC_F_POSX: case BCHMC_F_POSY: case BCHMC_F_POSZ:
+      k_positions<<<nblk_stride(h->g.N), 256, 0, h->stream>>>(h->g, make_pos(h, h->last_rsd), h->psi, h->ioq,
+                                                              (int)field - (int)BCHMC_F_POSX);
+      HIPCHK(hipGetLastError());
+      src = h->ioq;
+      break;
+    case BCHMC_F_RHO: src = h->rho; break;
+    case BCHMC_F_PART_LIKE: src = h->plike; break;
+    case BCHMC_F_VX: case BCHMC_F_VY: case BCHMC_F_VZ: src = h->V + ((int)field - (int)BCHMC_F_VX) * N; break;
+    case BCHMC_F_PSIX: case BCHMC_F_PSIY: case BCHMC_F_PSIZ: src = h->psi + ((int)field - (int)BCHMC_F_PSIX) * N; break;
+    case BCHMC_F_GRAD_PRIOR: src = h->gprior; break;
+    case BCHMC_F_GRAD_LIKE: src = h->glike; break;
+    default: return h->fail(BCHMC_ERR_ARG, "unknown field %d", (int)field);
+  }
+  if (!src) return h->fail(BCHMC_ERR_STATE, "field %d has not been computed", (int)field);
+  HIPCHK(hipMemcpyAsync(host, src, N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return BCHMC_OK;
+}
+
+int bchmc_profile(bchmc_handle *h, int enable) {
+  if (!h) return BCHMC_ERR_ARG;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  prof_collect(h);
+  h->prof_on = enable != 0;
+  return BCHMC_OK;
+}
+
+int bchmc_profile_read(bchmc_handle *h, double ms[BCHMC_K_COUNT], uint64_t launches[BCHMC_K_COUNT]) {
+  if (!h) return BCHMC_ERR_ARG;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  prof_collect(h);
+  for (int i = 0; i < BCHMC_K_COUNT; i++) {
+    if (ms) ms[i] = h->prof_ms[i];
+    if (launches) launches[i] = h->prof_n[i];
+    h->prof_ms[i] = 0.;
+    h->prof_n[i] = 0;
+  }
+  return BCHMC_OK;
+}
+
+}  // extern "C"

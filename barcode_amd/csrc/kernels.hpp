@@ -1,0 +1,539 @@
+// kernels.hpp -- HIP kernels of the bchmc engine (gfx950 / CDNA4, wave64, fp64).
+//
+// State lives in Fourier space: qk = R2C[q], pk = R2C[p] (unnormalised forward transforms, half-complex
+// n x n x (n/2+1), z fastest).  Everything that is diagonal in k (prior force S^-1 q, drift M^-1 p, the
+// Zel'dovich displacement kernel, the inverse-Laplacian-divergence of V, kicks) is done pointwise on those
+// arrays; only the particle-mesh part (displace, SPH scatter, likelihood partials, SPH-gradient gather)
+// runs in real space.  Reference lines restated by each kernel are cited at the kernel.
+#pragma once
+#include "common.hpp"
+
+namespace bchmc {
+
+// ------------------------------------------------------------------------------------------------------
+// Spectrum multipliers.  convolveInvCorrFuncWithSignal (HMC_help.cc:41-58) multiplies FFT[x] by
+// normFS / C(k) (0 where C <= 0) with C read from a FULL n^3 grid at index k + n*(j + n*i), k <= n/2.
+// We precompute that factor once per upload on the half-complex layout.
+// ------------------------------------------------------------------------------------------------------
+__global__ void k_prepare_mult(Geo g, const double *__restrict__ corr, double *__restrict__ mult, double normFS) {
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < g.Nh;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int k = (int)(idx % g.nh);
+    const long long ij = idx / g.nh;
+    const double c = corr[k + (long long)g.n * ij];
+    mult[idx] = (c > 0.0) ? normFS / c : 0.;
+  }
+}
+
+// Device-side trajectory control: the runaway-momentum guard of HMC.cc:360-364 without a host round trip.
+struct StepCtl {
+  int *stop;                        // set once the guard fired; later kernels leave (q, p) untouched
+  unsigned long long *steps_done;   // initialised to neps by the host
+  const double *guard_prev;         // sum over k of hw * Re p^(k) after the previous step (= N * p[0]); may be null
+  double guard_limit;               // 1e50 * N
+  unsigned long long step_index;    // number of completed steps if the guard fires now
+};
+
+// ------------------------------------------------------------------------------------------------------
+// First half kick + drift + Zel'dovich displacement kernel, all diagonal in k:
+//   p^ -= eps/2 * g^                          HMC.cc:293-294
+//   q^ += eps * (wM * p^ [+ extra])           HMC.cc:298-339 via HMC_help.cc:41-58 (extra = R2C[p/mass_r])
+//   Psi^_j = (k_j/k^2) * (Im phi^, -Re phi^)  EqSolvers.cc:208-268 with phi = -D1*deltaQ*q (Lag2Eul.cc:88)
+// c_za = -D1 * deltaQ_factor / N folds in the 1/N of the following C2R (fftwrapper.cc:99-101).
+// Psi^ is zero for k^2 <= 1e-14 and on every Nyquist plane.
+// ------------------------------------------------------------------------------------------------------
+__global__ void k_init_ctl(int *stop, unsigned long long *steps_done, unsigned long long neps) {
+  *stop = 0;
+  *steps_done = neps;
+}
+
+template <bool DRIFT>
+__global__ void __launch_bounds__(256)
+k_kick_drift_za(Geo g, double2 *__restrict__ qk, double2 *__restrict__ pk, const double2 *__restrict__ gk,
+                const double *__restrict__ wM, const double2 *__restrict__ extra, double2 *__restrict__ Ck,
+                double half_eps, double eps, double c_za, StepCtl ctl) {
+  if (DRIFT) {
+    if (*ctl.stop) return;
+    if (ctl.guard_prev && fabs(*ctl.guard_prev) > ctl.guard_limit) {
+      if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *ctl.steps_done = ctl.step_index;
+        __threadfence();
+        *ctl.stop = 1;
+      }
+      return;  // NB: *stop is only read by LATER kernels, every thread of this one takes this branch
+    }
+  }
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < g.Nh;
+       idx += (long long)gridDim.x * blockDim.x) {
+    double2 q = qk[idx];
+    if (DRIFT) {
+      double2 p = pk[idx];
+      const double2 gg = gk[idx];
+      p.x -= half_eps * gg.x;
+      p.y -= half_eps * gg.y;
+      pk[idx] = p;
+      double2 v = make_double2(0., 0.);
+      if (wM) {
+        const double w = wM[idx];
+        v.x = w * p.x;
+        v.y = w * p.y;
+      }
+      if (extra) {
+        const double2 e = extra[idx];
+        v.x += e.x;
+        v.y += e.y;
+      }
+      q.x += eps * v.x;
+      q.y += eps * v.y;
+      qk[idx] = q;
+    }
+    const int k = (int)(idx % g.nh);
+    const long long ij = idx / g.nh;
+    const int j = (int)(ij % g.n), i = (int)(ij / g.n);
+    const double kx = kval(i, g.n, g.kfac), ky = kval(j, g.n, g.kfac), kz = kval(k, g.n, g.kfac);
+    const double ksq = kx * kx + ky * ky + kz * kz;
+    double2 ox = make_double2(0., 0.), oy = ox, oz = ox;
+    const bool nyq = (i == g.n / 2) || (j == g.n / 2) || (k == g.n / 2);
+    if (ksq > 1.e-14 && !nyq) {
+      const double fac = 1. / ksq;
+      const double pr = c_za * q.x, pi = c_za * q.y;
+      const double fx = fac * kx, fy = fac * ky, fz = fac * kz;
+      ox = make_double2(fx * pi, fx * -pr);
+      oy = make_double2(fy * pi, fy * -pr);
+      oz = make_double2(fz * pi, fz * -pr);
+    }
+    Ck[idx] = ox;
+    Ck[idx + g.Nh] = oy;
+    Ck[idx + 2 * g.Nh] = oz;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Particle positions: disp_part (disp_part.cc:55-126) + plane-parallel RSD (rsd.cc:28-68, Lag2Eul.cc:378-401)
+// ------------------------------------------------------------------------------------------------------
+struct PosPar {
+  double d, L;
+  double cpecvel, v_norm;  // c_pecvel(a) and 1/Hub/a
+  int rsd, periodic;
+};
+
+__device__ __forceinline__ void particle_pos(const PosPar &pp, int i, int j, int k, double psx, double psy,
+                                             double psz, double &x, double &y, double &z) {
+  x = pp.d * (double)i + 0.5 * pp.d + psx;
+  y = pp.d * (double)j + 0.5 * pp.d + psy;
+  z = pp.d * (double)k + 0.5 * pp.d + psz;
+  if (pp.periodic) {
+    x = pacman(x, pp.L);
+    y = pacman(y, pp.L);
+    z = pacman(z, pp.L);
+  }
+  if (pp.rsd) {
+    const double vz = pp.cpecvel * psz;
+    z = z + vz * pp.v_norm;
+    if (pp.periodic) z = pacman(z, pp.L);
+  }
+}
+
+__global__ void k_positions(Geo g, PosPar pp, const double *__restrict__ psi, double *__restrict__ out, int comp) {
+  for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < g.N;
+       p += (long long)gridDim.x * blockDim.x) {
+    const int k = (int)(p % g.n);
+    const long long ij = p / g.n;
+    const int j = (int)(ij % g.n), i = (int)(ij / g.n);
+    double x, y, z;
+    particle_pos(pp, i, j, k, psi[p], psi[p + g.N], psi[p + 2 * g.N], x, y, z);
+    out[p] = comp == 0 ? x : (comp == 1 ? y : z);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// SPH mass assignment (getDensity_SPH, massFunctions.cc:392-495; kernel W_4 at 366-384).
+// One thread per particle; visits the (2*reach+1)^3 cube like the reference and keeps its `r/h <= 2`
+// decision, but rejects columns/cells on squared distance before paying for sqrt and the atomic.
+// ------------------------------------------------------------------------------------------------------
+struct SphPar {
+  double h, w_norm;  // kernel scale, 1/pi/h^3
+  double r2_lim;     // 4 h^2 (1 + 1e-12): beyond this r/h <= 2 cannot hold
+  double min1, min2, min3;
+  int reach;
+};
+
+__device__ __forceinline__ double sph_w(double q, double w_norm) {
+  // SPH_kernel_3D (massFunctions.cc:366-384)
+  if (q <= 1.) return w_norm * (1 - 3. / 2 * q * q + 3. / 4 * q * q * q);
+  const double t = 2. - q;
+  return w_norm * (1. / 4 * (t * t * t));
+}
+
+__global__ void __launch_bounds__(256)
+k_scatter_sph(Geo g, PosPar pp, SphPar sp, const double *__restrict__ psi, double *__restrict__ rho) {
+  const long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (p >= g.N) return;
+  const int k = (int)(p % g.n);
+  const long long ij = p / g.n;
+  const int j = (int)(ij % g.n), i = (int)(ij / g.n);
+  double x, y, z;
+  particle_pos(pp, i, j, k, psi[p], psi[p + g.N], psi[p + 2 * g.N], x, y, z);
+  // domain test, massFunctions.cc:426
+  if (!((x >= sp.min1 && x < sp.min1 + g.L) && (y >= sp.min2 && y < sp.min2 + g.L) &&
+        (z >= sp.min3 && z < sp.min3 + g.L)))
+    return;
+  const int n = g.n;
+  const double d = g.d;
+  const long long ix = (long long)(x / d), iy = (long long)(y / d), iz = (long long)(z / d);
+  const double ccx = ((double)ix + 0.5) * d, ccy = ((double)iy + 0.5) * d, ccz = ((double)iz + 0.5) * d;
+  const int R = sp.reach;
+  for (int i1 = -R; i1 <= R; ++i1) {
+    const double dx = x - (ccx + (double)i1 * d);
+    const double dx2 = dx * dx;
+    if (dx2 > sp.r2_lim) continue;
+    const long long kx = (ix + i1 + (long long)n * 4) % n;
+    for (int i2 = -R; i2 <= R; ++i2) {
+      const double dy = y - (ccy + (double)i2 * d);
+      const double r2ab = dx2 + dy * dy;
+      if (r2ab > sp.r2_lim) continue;
+      const long long ky = (iy + i2 + (long long)n * 4) % n;
+      double *row = rho + (long long)n * (ky + (long long)n * kx);
+      for (int i3 = -R; i3 <= R; ++i3) {
+        const double dz = z - (ccz + (double)i3 * d);
+        const double r2 = r2ab + dz * dz;
+        if (r2 > sp.r2_lim) continue;
+        const double r = sqrt(r2);
+        const double q = r / sp.h;
+        if (q <= 2.) {
+          const long long kz = (iz + i3 + (long long)n * 4) % n;
+          atomic_add_f64(row + kz, sph_w(q, sp.w_norm));
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Reductions
+// ------------------------------------------------------------------------------------------------------
+constexpr int kRedBlocks = 1024;  // fixed partial count -> deterministic two-stage sums
+
+__global__ void __launch_bounds__(256) k_sum(const double *__restrict__ a, long long n, double *__restrict__ partials) {
+  __shared__ double red[4];
+  double s = 0.;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    s += a[i];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+// Sum of the kRedBlocks partials, identical in every block that calls it (deterministic order).
+__device__ __forceinline__ double sum_partials(const double *__restrict__ partials, double *red) {
+  double s = 0.;
+  for (int i = threadIdx.x; i < kRedBlocks; i += blockDim.x) s += partials[i];
+  s = block_sum(s, red);
+  __shared__ double bc;
+  if (threadIdx.x == 0) bc = s;
+  __syncthreads();
+  return bc;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// overdens (massFunctions.cc:30-47) fused with the per-cell likelihood partial
+// (gaussian_independent.cpp:24-42, poissonian.cpp:19-34, lognormal_independent.cpp:40-55).
+// ------------------------------------------------------------------------------------------------------
+struct LikePar {
+  double rho_c, biasP, biasE, delta_min;
+  int likelihood;
+  int bias_is_identity;  // biasE == 1: pow(x, 1) == x and pow(x, 0) == 1 exactly, skip the pow calls
+};
+
+__device__ __forceinline__ double pow_bias(double x, const LikePar &lp) {
+  return lp.bias_is_identity ? x : pow(x, lp.biasE);
+}
+
+__global__ void __launch_bounds__(256)
+k_partial_like(Geo g, LikePar lp, const double *__restrict__ rho, const double *__restrict__ rho_partials,
+               const double *__restrict__ nobs, const double *__restrict__ noise, const double *__restrict__ window,
+               double *__restrict__ plike) {
+  __shared__ double red[4];
+  const double nmean = sum_partials(rho_partials, red) / (double)g.N;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < g.N;
+       i += (long long)gridDim.x * blockDim.x) {
+    const double dX = rho[i] / nmean - 1.;
+    const double w = window[i];
+    double out = 0.;
+    if (lp.likelihood == 1) {
+      const double Lambda = w * lp.rho_c * pow_bias(1. + lp.biasP * dX, lp);
+      if ((w > 0.) && (Lambda > 0.0)) {
+        const double s = noise[i];
+        out = (nobs[i] - Lambda) / (s * s);
+      }
+    } else if (lp.likelihood == 0) {
+      const double dens = 1. + lp.biasP * dX;
+      if ((w > 0.0) && (dens > 0.0)) {
+        const double Lambda = w * lp.rho_c * pow_bias(dens, lp);
+        const double dpow = lp.bias_is_identity ? 1. : pow(dens, lp.biasE - 1);
+        out = (1 - nobs[i] / Lambda) * lp.rho_c * lp.biasE * lp.biasP * dpow;
+      }
+    } else {  // 2: log-normal
+      if (w > 0.) {
+        const double Lambda = log(lp.rho_c * pow_bias(1. + lp.biasP * dX, lp));
+        const double s = noise[i];
+        out = (nobs[i] - Lambda) / (s * s);
+      }
+    }
+    plike[i] = out;
+  }
+}
+
+// -log L per cell summed per block (gaussian_independent.cpp:82-89, poissonian.cpp:62-71,
+// lognormal_independent.cpp:111-121); the host adds the kRedBlocks partials.
+__global__ void __launch_bounds__(256)
+k_loglike(Geo g, LikePar lp, const double *__restrict__ rho, const double *__restrict__ rho_partials,
+          const double *__restrict__ nobs, const double *__restrict__ noise, const double *__restrict__ window,
+          double *__restrict__ out_partials) {
+  __shared__ double red[4];
+  const double nmean = sum_partials(rho_partials, red) / (double)g.N;
+  double acc = 0.;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < g.N;
+       i += (long long)gridDim.x * blockDim.x) {
+    const double dX = rho[i] / nmean - 1.;
+    const double w = window[i];
+    if (lp.likelihood == 1) {
+      const double Lambda = w * lp.rho_c * pow_bias(1. + lp.biasP * dX, lp);
+      if ((w > 0.) && (Lambda > 0.0)) {
+        const double t = (Lambda - nobs[i]) / noise[i];
+        acc += 0.5 * (t * t);
+      }
+    } else if (lp.likelihood == 0) {
+      const double Lambda = w * lp.rho_c * pow_bias(1. + lp.biasP * dX, lp);
+      if ((w > 0.) && (Lambda > 0.0)) acc += Lambda - nobs[i] * log(Lambda);
+    } else {
+      double dc = dX;
+      if (dc < lp.delta_min) dc = lp.delta_min;
+      const double Lambda = log(lp.rho_c * (1. + dc));
+      if (w > 0.) {
+        const double resid = Lambda - nobs[i];
+        const double s = noise[i];
+        acc += 0.5 * resid * resid / (s * s);
+      }
+    }
+  }
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) out_partials[blockIdx.x] = acc;
+}
+
+__global__ void __launch_bounds__(256)
+k_overdens(Geo g, const double *__restrict__ rho, const double *__restrict__ rho_partials, double *__restrict__ out) {
+  __shared__ double red[4];
+  const double nmean = sum_partials(rho_partials, red) / (double)g.N;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < g.N;
+       i += (long long)gridDim.x * blockDim.x)
+    out[i] = rho[i] / nmean - 1.;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// SPH-kernel adjoint gather V(q) (likelihood_calc_V_SPH, HMC_models.cc:200-303; inner loop 77-128;
+// gradient of W_4 in h units, SPH_kernel.cpp:148-208).  Pure gather over the stencil hull
+// (SPH_kernel.cpp:110-139): `ncol` (i, j) columns with an inclusive k-range each.
+// ------------------------------------------------------------------------------------------------------
+struct HullPar {
+  const int4 *cols;  // {i, j, k_begin, k_last}
+  int ncol;
+  double h_inv, d_h;       // 1/h, d/h
+  double norm;             // 1 / (pi h^4)
+  double normalize;        // rho_c * V / N
+  double f1;               // fgrow(a), applied to V_z under RSD (HMC_models.cc:295-300)
+};
+
+__global__ void __launch_bounds__(256)
+k_gather_sph(Geo g, PosPar pp, HullPar hp, const double *__restrict__ psi, const double *__restrict__ plike,
+             double *__restrict__ V) {
+  extern __shared__ int4 s_cols[];
+  for (int m = threadIdx.x; m < hp.ncol; m += blockDim.x) s_cols[m] = hp.cols[m];
+  __syncthreads();
+  const long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (p >= g.N) return;
+  const int n = g.n;
+  const int k = (int)(p % n);
+  const long long ij = p / n;
+  const int j = (int)(ij % n), i = (int)(ij / n);
+  double px, py, pz;
+  particle_pos(pp, i, j, k, psi[p], psi[p + g.N], psi[p + 2 * g.N], px, py, pz);
+  const int ix = (int)(px / g.d), iy = (int)(py / g.d), iz = (int)(pz / g.d);
+  const double d_h = hp.d_h;
+  const double dpcx = px * hp.h_inv - ((double)ix + 0.5) * d_h;
+  const double dpcy = py * hp.h_inv - ((double)iy + 0.5) * d_h;
+  const double dpcz = pz * hp.h_inv - ((double)iz + 0.5) * d_h;
+  double ox = 0., oy = 0., oz = 0.;
+  for (int m = 0; m < hp.ncol; ++m) {
+    const int4 c = s_cols[m];
+    const double xh = dpcx - (double)c.x * d_h;
+    const double yh = dpcy - (double)c.y * d_h;
+    const double r2ab = xh * xh + yh * yh;
+    if (r2ab > 4.) continue;  // q_sq > 4 -> zero gradient for the whole column
+    const int kx = (ix + c.x + 4 * n) % n, ky = (iy + c.y + 4 * n) % n;
+    const double *row = plike + (long long)n * (ky + (long long)n * kx);
+    double zh = dpcz - (double)c.z * d_h;
+    for (int i3 = c.z; i3 <= c.w; ++i3) {
+      const double q_sq = r2ab + zh * zh;
+      if (q_sq <= 4.) {
+        const double q = sqrt(q_sq);
+        double partial;
+        if (q_sq > 1.) {
+          const double qm2 = q - 2.;
+          partial = -0.75 * qm2 * qm2 * hp.norm / q;
+        } else {
+          partial = (2.25 * q - 3.) * hp.norm;
+        }
+        const int kz = (iz + i3 + 4 * n) % n;
+        const double common = row[kz] * partial;
+        ox += common * xh;
+        oy += common * yh;
+        oz += common * zh;
+      }
+      zh -= d_h;
+    }
+  }
+  ox *= hp.normalize;
+  oy *= hp.normalize;
+  oz *= hp.normalize;
+  if (pp.rsd) oz += hp.f1 * oz;
+  V[p] = ox;
+  V[p + g.N] = oy;
+  V[p + 2 * g.N] = oz;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Force assembly in k-space + second half kick + guard sum.
+//   h^ = sum_j (k_j/k^2) (Im V^_j, -Re V^_j), Nyquist planes and k = 0 -> 0   gradient.cpp:167-210
+//   g^ = a * wS * q^ + b * h^                                                  HMC.cc:170-173,205; HMC_models.cc:458-470
+//   p^ -= c * g^                                                               HMC.cc:351-352
+// like_mode 0: h^ from the three V^ (calc_h 2/3); 1: h^ = Ck[0] as is (calc_h 1, GRF); 2: no likelihood term.
+// The guard slot receives sum_k hw_k Re p^_k = N * p[0] (HMC.cc:360).
+// ------------------------------------------------------------------------------------------------------
+template <bool KICK>
+__global__ void __launch_bounds__(256)
+k_assemble(Geo g, const double2 *__restrict__ Ck, const double2 *__restrict__ qk, const double *__restrict__ wS,
+           double2 *__restrict__ gk, double2 *__restrict__ pk, double a, double b, int like_mode, double c_kick,
+           double *guard_slot, const int *stop) {
+  __shared__ double red[4];
+  if (KICK && *stop) return;
+  double gsum = 0.;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < g.Nh;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int k = (int)(idx % g.nh);
+    double2 hk = make_double2(0., 0.);
+    if (like_mode == 0) {
+      const long long ij = idx / g.nh;
+      const int j = (int)(ij % g.n), i = (int)(ij / g.n);
+      const bool nyq = (i == g.n / 2) || (j == g.n / 2) || (k == g.n / 2);
+      const double kx = kval(i, g.n, g.kfac), ky = kval(j, g.n, g.kfac), kz = kval(k, g.n, g.kfac);
+      const double kmod = kx * kx + ky * ky + kz * kz;
+      if (kmod > 0 && !nyq) {
+        const double f = 1 / kmod;
+        const double2 vx = Ck[idx], vy = Ck[idx + g.Nh], vz = Ck[idx + 2 * g.Nh];
+        const double fx = kx * f, fy = ky * f, fz = kz * f;
+        hk.x = fx * vx.y + fy * vy.y + fz * vz.y;
+        hk.y = -(fx * vx.x) - fy * vy.x - fz * vz.x;
+      }
+    } else if (like_mode == 1) {
+      hk = Ck[idx];
+    }
+    double2 gg = make_double2(b * hk.x, b * hk.y);
+    if (a != 0.) {
+      const double2 q = qk[idx];
+      const double w = a * wS[idx];
+      gg.x += w * q.x;
+      gg.y += w * q.y;
+    }
+    gk[idx] = gg;
+    if (KICK) {
+      double2 p = pk[idx];
+      p.x -= c_kick * gg.x;
+      p.y -= c_kick * gg.y;
+      pk[idx] = p;
+      const double hw = (k == 0 || ((g.n & 1) == 0 && k == g.n / 2)) ? 1. : 2.;
+      gsum += hw * p.x;
+    }
+  }
+  if (KICK) {
+    gsum = block_sum(gsum, red);
+    if (threadIdx.x == 0) atomic_add_f64(guard_slot, gsum);
+  }
+}
+
+// sum_k hw_k * w_k * |x^_k|^2 per block: Parseval form of sum_x x * IFFT[w * FFT x]
+// (kinetic_term HMC.cc:101-115, prior_gaussian_log_prior gaussian.cpp:24-32).
+__global__ void __launch_bounds__(256)
+k_parseval(Geo g, const double2 *__restrict__ xk, const double *__restrict__ w, double *__restrict__ partials) {
+  __shared__ double red[4];
+  double s = 0.;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < g.Nh;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int k = (int)(idx % g.nh);
+    const double hw = (k == 0 || ((g.n & 1) == 0 && k == g.n / 2)) ? 1. : 2.;
+    const double2 x = xk[idx];
+    s += hw * w[idx] * (x.x * x.x + x.y * x.y);
+  }
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+__global__ void k_scale_c(long long n, const double2 *__restrict__ in, double2 *__restrict__ out, double s) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const double2 v = in[i];
+    out[i] = make_double2(v.x * s, v.y * s);
+  }
+}
+
+__global__ void k_add_r(long long n, const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ out) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    out[i] = a[i] + b[i];
+}
+
+// Real-space mass term: t = p / mass_r (0 where mass_r <= 0), HMC.cc:317-327.
+__global__ void k_div_mass_r(long long n, const double *__restrict__ p, const double *__restrict__ mass_r,
+                             double *__restrict__ out) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const double m = mass_r[i];
+    out[i] = (m > 0.0) ? p[i] * (1. / m) : 0.;
+  }
+}
+
+// sum 0.5 * p * (p / mass_r): real-space part of kinetic_term (HMC.cc:88-110)
+__global__ void __launch_bounds__(256)
+k_kin_rs(long long n, const double *__restrict__ p, const double *__restrict__ mass_r, double *__restrict__ partials) {
+  __shared__ double red[4];
+  double s = 0.;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const double m = mass_r[i];
+    const double invM = (m > 0.0) ? 1. / m : 0.;
+    s += 0.5 * p[i] * (invM * p[i]);
+  }
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+// GRF likelihood (gaussian_random_field.cpp:25-52): force (q - nobs)/sigma^2 and energy, window-masked.
+__global__ void k_grf_grad(long long n, const double *__restrict__ q, const double *__restrict__ nobs,
+                           const double *__restrict__ noise, const double *__restrict__ window,
+                           double *__restrict__ out) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const double s = noise[i];
+    out[i] = (window[i] > 0.) ? (q[i] - nobs[i]) / (s * s) : 0.;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_grf_loglike(long long n, const double *__restrict__ q, const double *__restrict__ nobs,
+              const double *__restrict__ noise, const double *__restrict__ window, double *__restrict__ partials) {
+  __shared__ double red[4];
+  double s = 0.;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    if (window[i] > 0.) {
+      const double t = (q[i] - nobs[i]) / noise[i];
+      s += 0.5 * (t * t);
+    }
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+}  // namespace bchmc

@@ -1,0 +1,154 @@
+/*
+ * bchmc.h -- C ABI of libbarcode_hip.so: MI355X-native engine for Barcode's HMC leapfrog hot path.
+ *
+ * This is the drop-in boundary.  Each entry point replaces a piece of the reference's C++ interface
+ * (paths under /root/reference/).  The engine owns all device state (rocFFT plans, grids in HBM);
+ * the caller owns every host array passed in and out.  One handle = one GPU = one Markov chain;
+ * calls on one handle are not re-entrant, different handles are independent.
+ *
+ * Error convention: every function returns 0 on success or a BCHMC_ERR_* code; bchmc_strerror() gives
+ * the text, bchmc_last_error() the detail of the last failure on a handle.  The reference throws
+ * std::runtime_error in the same situations (HMC_models.cc:316-319, 296-298; struct_hamil.h:309-312);
+ * the reference-side shim turns non-zero codes back into exceptions.
+ */
+#ifndef BCHMC_H
+#define BCHMC_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BCHMC_ABI_VERSION 1
+
+/* Scalars of HAMIL_NUMERICAL / HAMIL_DATA read by the path (barlib/include/struct_hamil.h:51-222);
+ * filled by the shim from the HAMIL_DATA that call_hamil.cc:42 builds.  Cubic grids only, like the
+ * reference (init_par.cc:116-118). */
+typedef struct bchmc_config {
+  uint32_t abi_version;      /* must be BCHMC_ABI_VERSION */
+  uint32_t Nx;               /* N1 = N2 = N3 */
+  double L;                  /* L1 = L2 = L3 [Mpc/h] */
+  double min1, min2, min3;   /* xllc, yllc, zllc */
+  double xobs, yobs, zobs;
+  int32_t planepar, periodic;
+  int32_t mk;                /* masskernel: 0 NGP, 1 CIC, 2 TSC, 3 SPH */
+  int32_t calc_h;            /* 1, 2 (SPH adjoint, default) or 3 (Fourier + TSC) */
+  int32_t likelihood;        /* 0 Poisson, 1 Gaussian, 2 log-normal, 3 GRF (init_par.cc:534-559) */
+  int32_t sfmodel;           /* 1 Zel'dovich (others only together with rsd_model) */
+  int32_t rsd_model;
+  int32_t mass_type;         /* 0,1,2,3,4,5,6,60 -> mass_fs/mass_rs as struct_hamil.h:272-313 */
+  int32_t correct_delta;
+  int32_t div_dH_by_N;
+  double particle_kernel_h;  /* SPH scale length, = particle_kernel_h_rel * cell size */
+  double grad_psi_prior_factor, grad_psi_likeli_factor, deltaQ_factor;
+  double rho_c, delta_min, biasP, biasE;
+  double ascale, D1, D2, OM, OL;
+  int32_t precision;         /* 0: fp64 fields (reference DOUBLE_PREC).  1 (fp32 fields): not yet built */
+  int32_t device;            /* HIP device ordinal */
+} bchmc_config;
+
+enum {
+  BCHMC_OK = 0,
+  BCHMC_ERR_ARG = 1,
+  BCHMC_ERR_MK_NOT_SPH = 2,       /* calc_h 2/3 need masskernel 3 (HMC_models.cc:316-319) */
+  BCHMC_ERR_RSD_NOT_PLANEPAR = 3, /* HMC_models.cc:296-298, rsd.cc:60-62 */
+  BCHMC_ERR_MASS_TYPE = 4,        /* struct_hamil.h:309-312 */
+  BCHMC_ERR_UNSUPPORTED = 5,
+  BCHMC_ERR_HIP = 6,
+  BCHMC_ERR_ROCFFT = 7,
+  BCHMC_ERR_NOMEM = 8,
+  BCHMC_ERR_STATE = 9             /* e.g. an input array was never uploaded */
+};
+
+/* Arrays of HAMIL_DATA (struct_hamil.h:146-166).  Inputs are uploaded once per chain (or when
+ * Hamiltonian_mass recomputes the mass, HMC.cc:400-423); outputs are fetched on demand. */
+typedef enum bchmc_field {
+  BCHMC_F_SIGNAL_PS = 0, /* in : prior power spectrum on the full N^3 grid (hd->signal_PS) */
+  BCHMC_F_MASS_F = 1,    /* in : Fourier-space mass (hd->mass_f), full N^3 grid */
+  BCHMC_F_MASS_R = 2,    /* in : real-space mass (hd->mass_r) */
+  BCHMC_F_NOBS = 3,      /* in : hd->nobs */
+  BCHMC_F_NOISE = 4,     /* in : hd->noise */
+  BCHMC_F_WINDOW = 5,    /* in : hd->window */
+  BCHMC_F_DELTAX = 6,    /* out: hd->deltaX of the last force / energy evaluation */
+  BCHMC_F_POSX = 7,      /* out: hd->posx */
+  BCHMC_F_POSY = 8,
+  BCHMC_F_POSZ = 9,
+  BCHMC_F_RHO = 10,      /* out (diagnostic): density before overdens() */
+  BCHMC_F_PART_LIKE = 11,/* out (diagnostic): partial_f_delta_x_log_like */
+  BCHMC_F_VX = 12,       /* out (diagnostic): likelihood_calc_V_SPH */
+  BCHMC_F_VY = 13,
+  BCHMC_F_VZ = 14,
+  BCHMC_F_PSIX = 15,     /* out (diagnostic): theta2vel displacement */
+  BCHMC_F_PSIY = 16,
+  BCHMC_F_PSIZ = 17,
+  BCHMC_F_GRAD_PRIOR = 18, /* out: prior term of the last bchmc_gradient (after its test factor) */
+  BCHMC_F_GRAD_LIKE = 19,  /* out: likelihood term of the last bchmc_gradient (after its test factor) */
+  BCHMC_F_COUNT = 20
+} bchmc_field;
+
+typedef struct bchmc_handle bchmc_handle;
+
+/* Lifecycle.  Replaces plan_pkg construction (fftwrapper.cc:281-324, init_par.cc:418-426) and the
+ * per-sample HAMIL_DATA setup (call_hamil.cc:38-42). */
+int bchmc_create(const bchmc_config *cfg, bchmc_handle **out);
+void bchmc_destroy(bchmc_handle *h);
+const char *bchmc_strerror(int code);
+const char *bchmc_last_error(const bchmc_handle *h);
+
+/* Host -> HBM copy of one input array of N = Nx^3 doubles. */
+int bchmc_upload(bchmc_handle *h, bchmc_field field, const double *host, size_t n);
+/* HBM -> host copy of one output array of N doubles (state of the last force / energy evaluation). */
+int bchmc_fetch(bchmc_handle *h, bchmc_field field, double *host, size_t n);
+
+/* Hamiltonian_EoM (HMC.cc:251-369): `neps` leapfrog steps of size `eps` from (q0, p0) to (q1, p1).
+ * The shim draws neps and eps from the caller's gsl_rng exactly as HMC.cc:260-264 and passes them in.
+ * *steps_done < neps iff the runaway-momentum guard |p[0]| > 1e50 (HMC.cc:360-364) fired. */
+int bchmc_leapfrog(bchmc_handle *h, const double *q0, const double *p0, double *q1, double *p1, double eps,
+                   uint64_t neps, uint64_t *steps_done);
+
+/* kinetic_term + psi (HMC.cc:64-143): out = { H_kin, psi_prior, psi_likeli } at (q, p).  Leaves
+ * deltaX / pos* of this evaluation in the handle like the reference's log_like does. */
+int bchmc_energies(bchmc_handle *h, const double *q, const double *p, double out[3]);
+
+/* delta_Hamiltonian (HMC.cc:209-248): terms = { H_kin_i, psi_prior_i, psi_likeli_i, H_kin_f,
+ * psi_prior_f, psi_likeli_f }, *dH includes div_dH_by_N. */
+int bchmc_delta_hamiltonian(bchmc_handle *h, const double *qi, const double *pi, const double *qf, const double *pf,
+                            double *dH, double terms[6]);
+
+/* gradient_psi (HMC.cc:146-206): g = prior_factor * S^-1 q + likeli_factor * d(-log L)/dq. */
+int bchmc_gradient(bchmc_handle *h, const double *q, double *g);
+
+/* Forward model only (Lag2Eul, Lag2Eul.cc:318-332 / 338-424): leaves deltaX and pos* in the handle.
+ * use_rsd < 0 means "as configured". */
+int bchmc_forward(bchmc_handle *h, const double *q, int use_rsd);
+
+/* ---- device-resident variants: same semantics, all pointers are HBM addresses on the handle's device,
+ * work is enqueued on the handle's stream and NOT synchronised (call bchmc_sync). ---- */
+int bchmc_leapfrog_device(bchmc_handle *h, const double *d_q0, const double *d_p0, double *d_q1, double *d_p1,
+                          double eps, uint64_t neps);
+int bchmc_steps_done(bchmc_handle *h, uint64_t *steps_done); /* synchronises */
+int bchmc_energies_device(bchmc_handle *h, const double *d_q, const double *d_p, double out[3]); /* synchronises */
+int bchmc_sync(bchmc_handle *h);
+void *bchmc_stream(bchmc_handle *h); /* hipStream_t the engine launches on */
+
+/* ---- measurement hooks (bench.py): per-kernel-class HIP-event timing on the engine's stream ---- */
+enum {
+  BCHMC_K_FFT_C2R = 0, BCHMC_K_FFT_R2C, BCHMC_K_KSPACE_DRIFT_ZA, BCHMC_K_SCATTER, BCHMC_K_MEAN_PARTIAL,
+  BCHMC_K_GATHER, BCHMC_K_KSPACE_FORCE_KICK, BCHMC_K_OTHER, BCHMC_K_COUNT
+};
+int bchmc_profile(bchmc_handle *h, int enable);                 /* 1: record events around every launch */
+int bchmc_profile_read(bchmc_handle *h, double ms[BCHMC_K_COUNT], uint64_t launches[BCHMC_K_COUNT]); /* and reset */
+const char *bchmc_kernel_name(int kernel_class);
+
+/* Cross-chain step-size statistics record: what each rank contributes per trajectory. */
+typedef struct bchmc_eps_record {
+  double epsilon;
+  int32_t accepted;
+  int32_t neps;
+} bchmc_eps_record;
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BCHMC_H */

@@ -1,0 +1,59 @@
+"""Shared helpers for the test-suite: seeded cases, error norms, golden-fixture I/O."""
+import os
+
+import numpy as np
+
+from barcode_amd import inputs
+from barcode_amd.params import HamilParams
+from oracle.oracle import Oracle
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+# fp64 tolerances stated by SURVEY.md 8d: rel-L2 of q1, p1 <= 1e-11 at 10 steps (<= 1e-9 at 100 steps),
+# energies rel <= 1e-10.  Intermediates of one force evaluation are held to 1e-12.
+TOL_FIELD = 1e-12
+TOL_TRAJ_10 = 1e-11
+TOL_ENERGY = 1e-10
+
+
+def rel_l2(a, b):
+    a = np.asarray(a, dtype=np.float64).ravel()
+    b = np.asarray(b, dtype=np.float64).ravel()
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+class Case:
+    """A seeded workload (SURVEY.md 8d recipe) plus an oracle context loaded with it."""
+
+    def __init__(self, Nx=16, L=None, window_zero_fraction=0.0, mass_r_seed=77, **kw):
+        L = float(L if L is not None else 200.0 * Nx / 64.0)  # same cell size as the 64^3 / 200 Mpc/h default
+        self.p = HamilParams(Nx=Nx, L=L, **kw)
+        p = self.p
+        f = inputs.make_fields(p)
+        self.signal_PS, self.mass_f = f["signal_PS"], f["mass_f"]
+        self.truth, self.q0, self.p0 = f["truth"], f["q0"], f["p0"]
+        self.mass_r = np.abs(inputs.gaussian_random_field(p, self.signal_PS, mass_r_seed)) + 0.5
+        self.oracle = Oracle(p)
+        self.oracle.set(signal_PS=self.signal_PS, mass_f=self.mass_f, mass_r=self.mass_r)
+        # mock data from the oracle's forward model of the truth field
+        if p.likelihood == 3:
+            dX = np.zeros(p.N)
+        else:
+            dX = self.oracle.Lag2Eul(self.truth, rsd=p.rsd_model if p.likelihood == 1 else 0)[0]
+        self.window, self.noise, self.nobs = inputs.mock_observations(p, dX.reshape((Nx,) * 3), delta_lag=self.truth)
+        if window_zero_fraction > 0:
+            rng = np.random.Generator(np.random.Philox(4242))
+            self.window = (rng.random(self.window.shape) >= window_zero_fraction).astype(np.float64)
+            self.nobs = self.nobs * self.window
+        self.oracle.set(window=self.window, noise=self.noise, nobs=self.nobs)
+        self.eps = 0.1 * p.eps_heuristic()
+
+    def arrays(self):
+        return dict(signal_PS=self.signal_PS, mass_f=self.mass_f, mass_r=self.mass_r, window=self.window,
+                    noise=self.noise, nobs=self.nobs)
+
+    def engine(self, device=0):
+        from barcode_amd.engine import Engine
+        e = Engine(self.p, device=device)
+        e.upload(**self.arrays())
+        return e
