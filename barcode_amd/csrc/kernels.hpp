@@ -357,6 +357,13 @@ k_gather_sph(Geo g, PosPar pp, HullPar hp, const double *__restrict__ psi, const
   const int j = (int)(ij % n), i = (int)(ij / n);
   double px, py, pz;
   particle_pos(pp, i, j, k, psi[p], psi[p + g.N], psi[p + 2 * g.N], px, py, pz);
+  // A non-finite position (blown-up trajectory) must not index out of bounds: such a particle gets V = 0.
+  if (!(px >= 0. && px <= g.L && py >= 0. && py <= g.L && pz >= 0. && pz <= g.L)) {
+    V[p] = 0.;
+    V[p + g.N] = 0.;
+    V[p + 2 * g.N] = 0.;
+    return;
+  }
   const int ix = (int)(px / g.d), iy = (int)(py / g.d), iz = (int)(pz / g.d);
   const double d_h = hp.d_h;
   const double dpcx = px * hp.h_inv - ((double)ix + 0.5) * d_h;

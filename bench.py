@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""bench.py -- HMC leapfrog steps/s on a 256^3 grid (BASELINE.json metric), one chain per GPU.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one leapfrog step (HMC.cc:284-365 body: half kick, M^-1 p, drift, one full force evaluation,
+half kick).  The timed region is ONE trajectory of exactly K steps through the C ABI
+(bchmc_leapfrog_device: state transforms + initial force + K steps + inverse transforms), with q0/p0 and all
+input grids already resident in HBM, bracketed by barrier + torch.cuda.synchronize().  Each rank runs its own
+independent chain (weak scaling); the only collective is the 16-byte/rank epsilon-statistics all-gather
+per trajectory (RCCL).  Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALGO_BYTES_PER_CELL_STEP = 544  # 68 real arrays x 8 B per leapfrog step (default force path)
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--nx", type=int, default=256, help="grid cells per axis (BASELINE config 3: 256)")
+    ap.add_argument("--likelihood", type=int, default=1)
+    ap.add_argument("--no-rsd", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-nx", type=int, default=0, help="grid of the CPU-baseline sample (default: same as --nx)")
+    ap.add_argument("--no-kernel-profile", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(params, case_arrays, q0, p0, eps):
+    """Oracle (kind "port", OpenMP build) timed on this box's host cores on a bounded sample of the same
+    workload: per-step time = (t(trajectory of 3 steps) - t(trajectory of 1 step)) / 2."""
+    from oracle.oracle import Oracle
+    cores = int(os.environ.get("OMP_NUM_THREADS", "1"))
+    o = Oracle(params, omp=True)
+    o.set(**case_arrays)
+    t0 = time.perf_counter()
+    o.Hamiltonian_EoM(q0, p0, eps, 1)
+    t1 = time.perf_counter()
+    o.Hamiltonian_EoM(q0, p0, eps, 3)
+    t2 = time.perf_counter()
+    o.close()
+    per_step = ((t2 - t1) - (t1 - t0)) / 2.0
+    return dict(value=1.0 / per_step, unit="steps/s", cores=cores, kind="port",
+                sample="oracle/liboracle_omp.so, %d^3 grid, same inputs: (t[3-step trajectory] - t[1-step trajectory])/2 "
+                       "= %.2f s per leapfrog step; %.1f s of CPU work in total" % (params.Nx, per_step, t2 - t0))
+
+
+def main():
+    args = parse()
+    # host threads for the CPU baseline (must be set before the OpenMP library loads)
+    try:
+        ncores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncores = os.cpu_count() or 1
+    os.environ.setdefault("OMP_NUM_THREADS", str(ncores))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if distributed:
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    if args.gpus != world and rank == 0:
+        print("bench.py: --gpus %d but WORLD_SIZE %d; running %d rank(s)" % (args.gpus, world, world), file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from barcode_amd import inputs
+    from barcode_amd.chains import ChainGroup, EpsRing
+    from barcode_amd.engine import Engine
+    from barcode_amd.params import HamilParams
+
+    rsd = 0 if args.no_rsd else 1
+    # BASELINE config 3: "256^3, 2LPT + RSD": under rsd_model the reference dispatches to Zel'dovich + plane-parallel
+    # RSD whatever sfmodel says; Gaussian likelihood, SPH kernel, calc_h 2, mass_type 1, fp64.
+    params = HamilParams(Nx=args.nx, L=200.0, likelihood=args.likelihood, rsd_model=rsd, sfmodel=2 if rsd else 1)
+    group = ChainGroup(pool=True, device=dev)
+    ring = EpsRing()
+
+    f = inputs.make_fields(params)
+    engine = Engine(params, device=local_rank)
+    engine.upload(signal_PS=f["signal_PS"], mass_f=f["mass_f"])
+    # mock data: forward model of the truth field on the GPU, then the reference's noise model
+    if params.likelihood != 3:
+        engine.upload(nobs=np.zeros(params.N), window=np.ones(params.N), noise=np.ones(params.N))
+        engine.forward(f["truth"], rsd if params.likelihood == 1 else 0)
+        dX = engine.fetch("deltaX").reshape((params.Nx,) * 3)
+    else:
+        dX = np.zeros((params.Nx,) * 3)
+    window, noise, nobs = inputs.mock_observations(params, dX, delta_lag=f["truth"])
+    engine.upload(window=window, noise=noise, nobs=nobs)
+    arrays = dict(signal_PS=f["signal_PS"], mass_f=f["mass_f"], window=window, noise=noise, nobs=nobs)
+
+    # independent chains: same data, different momenta per rank (seed + rank)
+    p0_host = inputs.gaussian_random_field(params, f["mass_f"], group.chain_seed(inputs.SEED_P0))
+    q0 = torch.from_numpy(f["q0"].reshape(-1)).to(dev)
+    p0 = torch.from_numpy(p0_host.reshape(-1)).to(dev)
+    q1, p1 = torch.empty_like(q0), torch.empty_like(p0)
+    eps = 0.5 * params.eps_heuristic()  # 0.5 * 2.38902581 * N^-0.57495347, fixed
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+
+    # ---- warmup (untimed) -------------------------------------------------------------------------
+    if args.warmup > 0:
+        engine.leapfrog_device(q0, p0, q1, p1, eps, args.warmup)
+        engine.sync()
+    stream = torch.cuda.ExternalStream(engine.stream, device=dev)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    # ---- timed: exactly K leapfrog steps -----------------------------------------------------------
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    engine.leapfrog_device(q0, p0, q1, p1, eps, args.steps)
+    ev1.record(stream)
+    done = engine.steps_done()  # synchronises the engine's stream
+    group.record_all(ring, eps, True, args.steps)  # the path's only collective: 16 B per rank per trajectory
+    torch.cuda.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+    wall = t1 - t0
+    gpu_ms = ev0.elapsed_time(ev1)
+    if distributed:
+        t = torch.tensor([wall], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    if done != args.steps:
+        print("bench.py: runaway guard fired after %d of %d steps" % (done, args.steps), file=sys.stderr)
+    finite = bool(torch.isfinite(q1).all().item() and torch.isfinite(p1).all().item())
+
+    # ---- per-kernel HIP-event breakdown (separate, untimed pass) -------------------------------------
+    kernels = None
+    if not args.no_kernel_profile:
+        ksteps = min(args.steps, 10)
+        engine.profile(True)
+        engine.leapfrog_device(q0, p0, q1, p1, eps, ksteps)
+        engine.sync()
+        prof = engine.profile_read()
+        engine.profile(False)
+        kernels = {k: dict(ms_per_step=round(ms / ksteps, 4), launches=n, avg_launch_ms=round(ms / max(n, 1), 4))
+                   for k, (ms, n) in prof.items() if n}
+
+    if rank == 0:
+        N = params.N
+        steps_total = args.steps * world
+        value = steps_total / wall
+        achieved = ALGO_BYTES_PER_CELL_STEP * N * args.steps / (gpu_ms * 1e-3) / 1e9  # per GPU, device time
+        out = {
+            "metric": "HMC leapfrog steps/sec on %d^3 grid" % params.Nx,
+            "value": round(value, 4),
+            "unit": "steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1e3 * wall / args.steps, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "%d^3 grid, L=200 Mpc/h, Gaussian prior, Zel'dovich%s (reference behaviour of '2LPT+RSD', "
+                            "SURVEY M3), likelihood=%d, SPH mass kernel (mk=3), calc_h=2, mass_type=1, fp64; one "
+                            "trajectory of %d leapfrog steps per chain" % (params.Nx, " + plane-parallel RSD" if rsd else "",
+                                                                           params.likelihood, args.steps),
+                "grid": params.Nx, "chains": world, "parallelism": "independent chains, 1 per GPU",
+                "eps": eps, "steps_done": int(done), "finite": finite,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "whole leapfrog step (all kernels + 6 rocFFT transforms)",
+                "achieved": round(achieved, 2),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5),
+                "traffic": None,
+                "algorithmic_bytes_per_step": ALGO_BYTES_PER_CELL_STEP * N,
+                "device_ms_per_step": round(gpu_ms / args.steps, 4),
+                "kernels": kernels,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cpu_params = params
+            cq0, cp0, carr = f["q0"], p0_host, arrays
+            if args.cpu_nx and args.cpu_nx != params.Nx:
+                from tests.util import Case  # small-grid sample of the same recipe
+                c = Case(Nx=args.cpu_nx, L=200.0 * args.cpu_nx / params.Nx, likelihood=params.likelihood,
+                         rsd_model=rsd)
+                cpu_params, cq0, cp0, carr = c.p, c.q0, c.p0, c.arrays()
+            out["cpu_baseline"] = cpu_baseline(cpu_params, carr, cq0, cp0, eps)
+        print(json.dumps(out))
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -709,6 +709,12 @@ int orc_likelihood_calc_V_SPH(orc_hamil *h, const double *part_like, const doubl
 #pragma omp parallel for
   for (long j = 0; j < (long)h->N; j++) {
     double px = posx[j], py = posy[j], pz = posz[j];
+    /* Not in the reference: a non-finite position (blown-up trajectory) would index out of bounds below
+     * (undefined behaviour upstream); the oracle and the engine both give such a particle V = 0. */
+    if (!(px >= 0. && px <= h->L1 && py >= 0. && py <= h->L2 && pz >= 0. && pz <= h->L3)) {
+      out_x[j] = out_y[j] = out_z[j] = 0.;
+      continue;
+    }
     int ix = (int)(px / d1), iy = (int)(py / d2), iz = (int)(pz / d3);
     double ccx_h = ((double)ix + 0.5) * d1_h, ccy_h = ((double)iy + 0.5) * d2_h, ccz_h = ((double)iz + 0.5) * d3_h;
     double dpcx_h = px * h_inv - ccx_h, dpcy_h = py * h_inv - ccy_h, dpcz_h = pz * h_inv - ccz_h;

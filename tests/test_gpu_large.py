@@ -1,0 +1,129 @@
+"""BASELINE-size checks on the GPU: direct oracle comparison where the oracle finishes in seconds
+(64^3, 128^3), size-independent properties at 256^3 (reversibility, Parseval/real-space energy agreement,
+mass conservation, linearity of the prior force, determinism of everything but the atomic scatter)."""
+import numpy as np
+import pytest
+
+from barcode_amd import inputs
+from barcode_amd.params import HamilParams
+from tests.util import TOL_ENERGY, TOL_TRAJ_10, Case, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def test_config1_64cubed_ten_steps_against_oracle():
+    """BASELINE config 1: 64^3, Gaussian prior + Zel'dovich, Gaussian likelihood, 10 leapfrog steps, fp64."""
+    c = Case(Nx=64, L=200.0, likelihood=1, rsd_model=0)
+    c.oracle.close()
+    from oracle.oracle import Oracle
+    o = Oracle(c.p, omp=True)
+    o.set(**c.arrays())
+    e = c.engine()
+    q1o, p1o, _ = o.Hamiltonian_EoM(c.q0, c.p0, c.eps, 10)
+    q1, p1, done = e.leapfrog(c.q0, c.p0, c.eps, 10)
+    assert done == 10
+    assert rel_l2(q1, q1o) < TOL_TRAJ_10 and rel_l2(p1, p1o) < TOL_TRAJ_10
+    dHo, to = o.delta_Hamiltonian(c.q0, c.p0, q1o, p1o)
+    dH, t = e.delta_hamiltonian(c.q0, c.p0, q1o, p1o)
+    assert np.all(np.abs(t - to) <= TOL_ENERGY * np.abs(to))
+    e.close()
+
+
+def test_config2_128cubed_poisson_against_oracle():
+    """BASELINE config 2 shape (128^3, Poissonian likelihood) on a 2-step sample the oracle finishes quickly."""
+    c = Case(Nx=128, L=200.0, likelihood=0, rsd_model=0)
+    c.oracle.close()
+    from oracle.oracle import Oracle
+    o = Oracle(c.p, omp=True)
+    o.set(**c.arrays())
+    e = c.engine()
+    q1o, p1o, _ = o.Hamiltonian_EoM(c.q0, c.p0, c.eps, 2)
+    q1, p1, done = e.leapfrog(c.q0, c.p0, c.eps, 2)
+    assert done == 2
+    assert rel_l2(q1, q1o) < TOL_TRAJ_10 and rel_l2(p1, p1o) < TOL_TRAJ_10
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def big():
+    """BASELINE config 3 at full size: 256^3, Zel'dovich + plane-parallel RSD, Gaussian likelihood."""
+    from barcode_amd.engine import Engine
+    p = HamilParams(Nx=256, L=200.0, likelihood=1, rsd_model=1, sfmodel=2)
+    f = inputs.make_fields(p)
+    e = Engine(p)
+    e.upload(signal_PS=f["signal_PS"], mass_f=f["mass_f"], nobs=np.zeros(p.N), window=np.ones(p.N),
+             noise=np.ones(p.N))
+    e.forward(f["truth"], 1)
+    dX = e.fetch("deltaX").reshape((p.Nx,) * 3)
+    window, noise, nobs = inputs.mock_observations(p, dX)
+    e.upload(window=window, noise=noise, nobs=nobs)
+    yield p, f, e, dX
+    e.close()
+
+
+def test_256_mass_conservation_and_overdensity(big):
+    p, f, e, dX = big
+    rho = e.fetch("rho")
+    # every particle deposits sum_cells W ~ 1/d^3 (kernel sampled at cell centres): total within a per cent of N/d^3
+    assert abs(rho.sum() * p.d ** 3 / p.N - 1.0) < 0.02
+    assert rho.min() >= 0.0
+    assert abs(dX.mean()) < 1e-12          # overdens() removes the mean exactly
+    assert dX.min() >= -1.0
+
+
+def test_256_reversibility(big):
+    """Leapfrog is time-reversible: integrate, flip p, integrate back -> the start, to round-off
+    (amplified by the trajectory's own sensitivity, hence 1e-8)."""
+    p, f, e, _ = big
+    eps = 0.25 * p.eps_heuristic()
+    q1, p1, done = e.leapfrog(f["q0"], f["p0"], eps, 5)
+    assert done == 5
+    q2, p2, done = e.leapfrog(q1, -p1, eps, 5)
+    assert rel_l2(q2, f["q0"]) < 1e-8
+    assert rel_l2(-p2, f["p0"]) < 1e-8
+
+
+def test_256_energy_terms_against_real_space_evaluation(big):
+    """The engine evaluates 1/2 x^T A x by Parseval in k-space; compare with the reference's real-space form
+    0.5 * sum(x * IFFT[w FFT x]) (HMC.cc:101-115, gaussian.cpp:24-32) computed with numpy, and the Gaussian
+    -log L from the fetched deltaX (gaussian_independent.cpp:82-89)."""
+    p, f, e, _ = big
+    K, prior, like = e.energies(f["q0"], f["p0"])
+    n = p.Nx
+    normFS = p.L ** 3 / p.N
+
+    def quad(x, spec):
+        s = spec[:, :, : n // 2 + 1]
+        w = np.zeros_like(s)
+        np.divide(normFS, s, out=w, where=s > 0)
+        y = np.fft.irfftn(np.fft.rfftn(x) * w, s=(n, n, n), axes=(0, 1, 2))
+        return 0.5 * float(np.sum(x * y))
+
+    assert abs(K - quad(f["p0"], f["mass_f"])) <= 1e-10 * abs(K)
+    assert abs(prior - quad(f["q0"], f["signal_PS"])) <= 1e-10 * abs(prior)
+    dX = e.fetch("deltaX")
+    nobs, noise = e.fetch("nobs"), e.fetch("noise")
+    lam = p.rho_c * (1.0 + dX)
+    ref = float(np.sum(np.where(lam > 0, 0.5 * ((lam - nobs) / noise) ** 2, 0.0)))
+    assert abs(like - ref) <= 1e-10 * abs(ref)
+
+
+def test_256_prior_force_is_linear_and_likelihood_factor_scales(big):
+    p, f, e, _ = big
+    e.gradient(f["q0"])
+    gp1, gl1 = e.fetch("grad_prior"), e.fetch("grad_like")
+    e.gradient(2.0 * f["q0"])
+    gp2 = e.fetch("grad_prior")
+    assert rel_l2(gp2, 2.0 * gp1) < 1e-13
+    # repeated evaluation: identical up to the atomic-add order of the scatter
+    e.gradient(f["q0"])
+    assert rel_l2(e.fetch("grad_like"), gl1) < 1e-12
+    assert np.array_equal(e.fetch("grad_prior"), gp1)
+
+
+def test_256_small_step_conserves_energy(big):
+    p, f, e, _ = big
+    eps = 0.02 * p.eps_heuristic()
+    q1, p1, _ = e.leapfrog(f["q0"], f["p0"], eps, 4)
+    dH, terms = e.delta_hamiltonian(f["q0"], f["p0"], q1, p1)
+    assert abs(dH) < 1e-4 * abs(terms[:3].sum())

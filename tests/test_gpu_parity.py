@@ -1,0 +1,172 @@
+"""Parity of the HIP engine (through the C ABI) with the CPU oracle on identical seeded inputs.
+
+fp64 tolerances (written out in tests/util.py): intermediates of one force evaluation
+rel-L2 <= 1e-12, final (q, p) of a 10-step trajectory rel-L2 <= 1e-11, energies rel <= 1e-10.
+The engine's scatter uses fp64 hardware atomics (order-dependent in the last bits), hence tolerances
+instead of bit-exactness; the reference has the same property under OpenMP (main.cc:86-90).
+"""
+import numpy as np
+import pytest
+
+from tests.util import TOL_ENERGY, TOL_FIELD, TOL_TRAJ_10, Case, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = [
+    dict(likelihood=1, rsd_model=0),                       # BASELINE config 1 (Gaussian, Zel'dovich)
+    dict(likelihood=0, rsd_model=0),                       # config 2 (Poissonian)
+    dict(likelihood=1, rsd_model=1, sfmodel=2),            # config 3 ("2LPT + RSD" == Zel'dovich + RSD)
+    dict(likelihood=2, rsd_model=0),                       # log-normal likelihood
+    dict(likelihood=3, rsd_model=0),                       # GRF likelihood
+    dict(likelihood=1, rsd_model=0, mass_type=0),          # real-space mass only
+    dict(likelihood=1, rsd_model=0, mass_type=5),          # Fourier + real-space mass
+    dict(likelihood=1, rsd_model=0, calc_h=1),             # h = partial_f (HMC_models.cc:413-415)
+    dict(likelihood=1, rsd_model=1, deltaQ_factor=0.9, grad_psi_prior_factor=0.5, grad_psi_likeli_factor=2.0,
+         correct_delta=0),                                 # test factors (HMC.cc:170-173, HMC_models.cc:461-468)
+]
+
+
+@pytest.fixture(scope="module", params=range(len(CONFIGS)), ids=lambda i: "cfg%d" % i)
+def case(request):
+    kw = CONFIGS[request.param]
+    c = Case(Nx=16, **kw)
+    c.e = c.engine()
+    yield c
+    c.e.close()
+
+
+def test_forward_model_intermediates(case):
+    """theta2vel -> disp_part (-> calc_pos_rsd) -> getDensity_SPH -> overdens."""
+    c = case
+    if c.p.likelihood == 3:
+        pytest.skip("GRF likelihood has no forward model")
+    rsd = c.p.rsd_model
+    dX, px, py, pz = c.oracle.Lag2Eul(c.truth, rsd=rsd)
+    c.e.forward(c.truth, rsd)
+    psi = c.oracle.theta2vel(-c.p.D1 * c.truth.ravel())
+    for name, ref in zip(("psix", "psiy", "psiz"), psi):
+        assert rel_l2(c.e.fetch(name), ref) < TOL_FIELD
+    for name, ref in zip(("posx", "posy", "posz"), (px, py, pz)):
+        assert rel_l2(c.e.fetch(name), ref) < TOL_FIELD
+    rho = c.oracle.getDensity(3, px, py, pz)
+    assert rel_l2(c.e.fetch("rho"), rho) < TOL_FIELD
+    assert rel_l2(c.e.fetch("deltaX"), dX) < TOL_FIELD
+
+
+def test_gradient_psi_and_its_pieces(case):
+    c = case
+    g, gp, gl = c.oracle.gradient_psi(c.q0)
+    gg = c.e.gradient(c.q0)
+    assert rel_l2(c.e.fetch("grad_prior"), gp) < TOL_FIELD
+    assert rel_l2(c.e.fetch("grad_like"), gl) < 10 * TOL_FIELD
+    assert rel_l2(gg, g) < 10 * TOL_FIELD
+    if c.p.likelihood != 3:
+        dX = c.oracle.get("deltaX")
+        assert rel_l2(c.e.fetch("deltaX"), dX) < TOL_FIELD
+        pl = c.oracle.partial_f_delta_x_log_like(dX)
+        assert rel_l2(c.e.fetch("part_like"), pl) < 10 * TOL_FIELD
+        if c.p.calc_h == 2:
+            pos = [c.oracle.get(k) for k in ("posx", "posy", "posz")]
+            V = c.oracle.likelihood_calc_V_SPH(pl, *pos)
+            for name, ref in zip(("Vx", "Vy", "Vz"), V):
+                assert rel_l2(c.e.fetch(name), ref) < 10 * TOL_FIELD
+
+
+def test_ten_step_trajectory(case):
+    """One leapfrog trajectory's final (q, p) on identical inputs (BASELINE north_star correctness gate)."""
+    c = case
+    q1o, p1o, done_o = c.oracle.Hamiltonian_EoM(c.q0, c.p0, c.eps, 10)
+    q1, p1, done = c.e.leapfrog(c.q0, c.p0, c.eps, 10)
+    assert done == done_o == 10
+    assert rel_l2(q1, q1o) < TOL_TRAJ_10
+    assert rel_l2(p1, p1o) < TOL_TRAJ_10
+
+
+def test_delta_hamiltonian(case):
+    c = case
+    q1o, p1o, _ = c.oracle.Hamiltonian_EoM(c.q0, c.p0, c.eps, 3)
+    dHo, to = c.oracle.delta_Hamiltonian(c.q0, c.p0, q1o, p1o)
+    dH, t = c.e.delta_hamiltonian(c.q0, c.p0, q1o, p1o)
+    assert np.all(np.abs(t - to) <= TOL_ENERGY * np.abs(to))
+    assert abs(dH - dHo) <= 1e-9 * max(abs(to).max(), 1.0)
+    # hd->deltaX holds the LAST evaluation, i.e. psi(signalf) (HMC.cc:225)
+    if c.p.likelihood != 3:
+        assert rel_l2(c.e.fetch("deltaX"), c.oracle.get("deltaX")) < TOL_FIELD
+
+
+def test_div_dH_by_N():
+    c = Case(Nx=16, div_dH_by_N=1)
+    e = c.engine()
+    q1, p1, _ = c.oracle.Hamiltonian_EoM(c.q0, c.p0, c.eps, 2)
+    dHo, _ = c.oracle.delta_Hamiltonian(c.q0, c.p0, q1, p1)
+    dH, _ = e.delta_hamiltonian(c.q0, c.p0, q1, p1)
+    assert abs(dH - dHo) < 1e-9 * max(abs(dHo), 1e-3)
+    e.close()
+
+
+@pytest.mark.parametrize("nx", [8, 32])
+def test_other_grid_sizes(nx):
+    c = Case(Nx=nx, likelihood=1, rsd_model=1)
+    e = c.engine()
+    q1o, p1o, _ = c.oracle.Hamiltonian_EoM(c.q0, c.p0, c.eps, 5)
+    q1, p1, done = e.leapfrog(c.q0, c.p0, c.eps, 5)
+    assert done == 5
+    assert rel_l2(q1, q1o) < TOL_TRAJ_10 and rel_l2(p1, p1o) < TOL_TRAJ_10
+    e.close()
+
+
+def test_window_with_holes_and_empty_cells():
+    """Masked cells (window = 0) and zero counts contribute nothing (gaussian_independent.cpp:34-40)."""
+    c = Case(Nx=16, likelihood=0, window_zero_fraction=0.4)
+    e = c.engine()
+    g, _, _ = c.oracle.gradient_psi(c.q0)
+    assert rel_l2(e.gradient(c.q0), g) < 10 * TOL_FIELD
+    e.close()
+
+
+def test_runaway_guard_matches_reference_semantics():
+    """HMC.cc:360-364: the loop ends after the first step whose |p[0]| exceeds 1e50."""
+    c = Case(Nx=16)
+    e = c.engine()
+    p0 = c.p0.copy().ravel()
+    p0[0] = 1e60
+    q1o, p1o, done_o = c.oracle.Hamiltonian_EoM(c.q0, p0, 1e-6, 5)
+    q1, p1, done = e.leapfrog(c.q0, p0, 1e-6, 5)
+    assert done == done_o == 1
+    assert rel_l2(p1, p1o) < 1e-10
+    # and a normal trajectory afterwards is unaffected by the tripped flag
+    _, _, done2 = e.leapfrog(c.q0, c.p0, c.eps, 3)
+    assert done2 == 3
+    e.close()
+
+
+def test_epsilon_is_clipped_at_two():
+    """HMC.cc:263-264."""
+    c = Case(Nx=8, likelihood=3)
+    e = c.engine()
+    a = e.leapfrog(c.q0, c.p0, 2.0, 1)
+    b = e.leapfrog(c.q0, c.p0, 5.0, 1)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    e.close()
+
+
+def test_error_conventions():
+    """Same failure conditions as the reference's runtime_errors, as return codes."""
+    from barcode_amd.engine import BchmcError, Engine
+    from barcode_amd.params import HamilParams
+    c = Case(Nx=8, mk=1)  # CIC + calc_h 2: HMC_models.cc:316-319
+    with pytest.raises(BchmcError) as ei:
+        e = c.engine()
+        e.gradient(c.q0)
+    assert ei.value.code in (2, 5)
+    with pytest.raises(BchmcError) as ei:
+        Engine(HamilParams(Nx=8, mass_type=7))
+    assert ei.value.code == 4
+    with pytest.raises(BchmcError) as ei:
+        Engine(HamilParams(Nx=8)).gradient(np.zeros(512))  # nothing uploaded
+    assert ei.value.code == 9
+    with pytest.raises(BchmcError) as ei:
+        c2 = Case(Nx=8, rsd_model=1)
+        c2.p.planepar = 0
+        c2.engine().gradient(c2.q0)
+    assert ei.value.code == 3
