@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -68,6 +69,14 @@ struct bchmc_handle {
   int4 *hull = nullptr;
   int hull_n = 0;
   int reach = 0;
+  // tile-sorted particle-mesh path
+  bool tiled = false;
+  TilePar tp{};
+  int *t_cnt = nullptr, *t_off = nullptr, *t_woff = nullptr;  // ntiles, ntiles+1, ntiles+1
+  int2 *t_rank = nullptr;                                      // N
+  double *sx = nullptr, *sy = nullptr, *sz = nullptr;          // N each: sorted positions
+  int *sidx = nullptr;                                         // N: original index | flags
+  bool sorted_valid = false;
   bool have_eval = false;  // rho / psi hold a forward evaluation
   int last_rsd = 0;
 
@@ -193,6 +202,7 @@ PosPar make_pos(const bchmc_handle *h, int rsd) {
 SphPar make_sph(const bchmc_handle *h) {
   SphPar sp;
   sp.h = h->c.particle_kernel_h;
+  sp.h_inv = 1. / sp.h;
   sp.w_norm = 1. / M_PI / (sp.h * sp.h * sp.h);
   sp.r2_lim = 4. * sp.h * sp.h * (1. + 1e-12);
   sp.min1 = h->c.min1;
@@ -295,10 +305,28 @@ int launch_za(bchmc_handle *h, double dq_factor) {
 int forward_rest(bchmc_handle *h, int rsd) {
   if (rsd && !h->c.planepar) return h->fail(BCHMC_ERR_RSD_NOT_PLANEPAR, "non-plane-parallel RSD is not implemented");
   CHK(fft_exec(h, h->c2r3, h->Ck, h->psi, BCHMC_K_FFT_C2R));
+  h->sorted_valid = false;
+  if (h->c.mk == 3 && h->tiled) {
+    // counting sort of the particles by the Eulerian tile of their home cell
+    ProfScope ps(h, BCHMC_K_SORT);
+    HIPCHK(hipMemsetAsync(h->t_cnt, 0, h->tp.ntiles * sizeof(int), h->stream));
+    const PosPar pp = make_pos(h, rsd);
+    k_bin<<<nblk_full(h->g.N), 256, 0, h->stream>>>(h->g, pp, make_sph(h), h->tp, h->psi, h->t_cnt, h->t_rank, h->V);
+    k_scan_tiles<<<1, 1024, 0, h->stream>>>(h->tp, h->t_cnt, h->t_off, h->t_woff);
+    k_reorder<<<nblk_full(h->g.N), 256, 0, h->stream>>>(h->g, pp, h->psi, h->t_rank, h->t_off, h->sx, h->sy, h->sz,
+                                                        h->sidx);
+    HIPCHK(hipGetLastError());
+    h->sorted_valid = true;
+  }
   {
     ProfScope ps(h, BCHMC_K_SCATTER);
     HIPCHK(hipMemsetAsync(h->rho, 0, h->g.N * sizeof(double), h->stream));
-    if (h->c.mk == 3) {
+    if (h->c.mk == 3 && h->tiled) {
+      const int grid = h->tp.ntiles + (int)(h->g.N / h->tp.chunk) + 1;  // upper bound on (tile, chunk) work items
+      const size_t lds = (size_t)h->tp.lx * h->tp.ly * h->tp.lz * sizeof(double);
+      k_scatter_tile<<<grid, 256, lds, h->stream>>>(h->g, make_sph(h), h->tp, h->sx, h->sy, h->sz, h->sidx, h->t_off,
+                                                    h->t_woff, h->rho);
+    } else if (h->c.mk == 3) {
       k_scatter_sph<<<nblk_full(h->g.N), 256, 0, h->stream>>>(h->g, make_pos(h, rsd), make_sph(h), h->psi, h->rho);
     } else {
       return h->fail(BCHMC_ERR_UNSUPPORTED, "masskernel %d not built yet (only 3 = SPH)", h->c.mk);
@@ -339,8 +367,16 @@ int like_force(bchmc_handle *h, int *like_mode) {
   {
     ProfScope ps(h, BCHMC_K_GATHER);
     HullPar hp = make_hull(h);
-    k_gather_sph<<<nblk_full(h->g.N), 256, hp.ncol * sizeof(int4), h->stream>>>(h->g, make_pos(h, h->last_rsd), hp,
-                                                                                h->psi, h->plike, h->V);
+    if (h->tiled && h->sorted_valid) {
+      const int grid = h->tp.ntiles + (int)(h->g.N / h->tp.chunk) + 1;
+      const size_t ncell = (size_t)h->tp.lx * h->tp.ly * h->tp.lz;
+      const size_t lds = ((ncell + 1) & ~(size_t)1) * sizeof(double) + hp.ncol * sizeof(int4);
+      k_gather_tile<<<grid, 256, lds, h->stream>>>(h->g, hp, h->tp, h->last_rsd, h->sx, h->sy, h->sz, h->sidx,
+                                                   h->t_off, h->t_woff, h->plike, h->V);
+    } else {
+      k_gather_sph<<<nblk_full(h->g.N), 256, hp.ncol * sizeof(int4), h->stream>>>(h->g, make_pos(h, h->last_rsd), hp,
+                                                                                  h->psi, h->plike, h->V);
+    }
     HIPCHK(hipGetLastError());
   }
   CHK(fft_exec(h, h->r2c3, h->V, h->Ck, BCHMC_K_FFT_R2C));
@@ -584,7 +620,7 @@ const char *bchmc_last_error(const bchmc_handle *h) { return h ? h->err.c_str() 
 
 const char *bchmc_kernel_name(int cls) {
   static const char *names[BCHMC_K_COUNT] = {"rocfft_c2r", "rocfft_r2c",        "k_kick_drift_za", "k_scatter_sph",
-                                            "k_sum+k_partial_like", "k_gather_sph", "k_assemble",      "other"};
+                                            "k_sum+k_partial_like", "k_gather_sph", "k_assemble", "k_bin+k_scan_tiles+k_reorder", "other"};
   return (cls >= 0 && cls < BCHMC_K_COUNT) ? names[cls] : "?";
 }
 
@@ -669,6 +705,37 @@ int bchmc_create(const bchmc_config *cfg, bchmc_handle **out) {
     h->hull_n = (int)cols.size();
     CHK(dev_alloc(h, &h->hull, cols.size()));
     HIPCHK(hipMemcpy(h->hull, cols.data(), cols.size() * sizeof(int4), hipMemcpyHostToDevice));
+    // tile-sorted particle-mesh path: tiles of 8 x 8 x 16 cells (z fastest) when they divide the grid
+    {
+      TilePar &tp = h->tp;
+      const int n = g.n;
+      tp.tx = tp.ty = (n % 8 == 0) ? 8 : ((n % 4 == 0) ? 4 : 0);
+      tp.tz = (n % 16 == 0) ? 16 : tp.tx;
+      const bool want = (cfg->mk == 3) && tp.tx > 0 && !std::getenv("BCHMC_NO_TILES");
+      if (want) {
+        tp.ntx = n / tp.tx;
+        tp.nty = n / tp.ty;
+        tp.ntz = n / tp.tz;
+        tp.ntiles = tp.ntx * tp.nty * tp.ntz;
+        tp.R = h->reach;
+        tp.lx = tp.tx + 2 * tp.R;
+        tp.ly = tp.ty + 2 * tp.R;
+        tp.lz = tp.tz + 2 * tp.R;
+        tp.chunk = 2048;
+        const size_t lds = (size_t)tp.lx * tp.ly * tp.lz * sizeof(double) + cols.size() * sizeof(int4) + 16;
+        if (lds <= 64 * 1024 && g.N < (1ll << 30)) {
+          h->tiled = true;
+          CHK(dev_alloc(h, &h->t_cnt, (size_t)tp.ntiles));
+          CHK(dev_alloc(h, &h->t_off, (size_t)tp.ntiles + 1));
+          CHK(dev_alloc(h, &h->t_woff, (size_t)tp.ntiles + 1));
+          CHK(dev_alloc(h, &h->t_rank, N));
+          CHK(dev_alloc(h, &h->sx, N));
+          CHK(dev_alloc(h, &h->sy, N));
+          CHK(dev_alloc(h, &h->sz, N));
+          CHK(dev_alloc(h, &h->sidx, N));
+        }
+      }
+    }
     HIPCHK(hipStreamSynchronize(h->stream));
     return BCHMC_OK;
   };
@@ -687,7 +754,7 @@ void bchmc_destroy(bchmc_handle *h) {
   if (h->info) rocfft_execution_info_destroy(h->info);
   void *ptrs[] = {h->work, h->wS,  h->wM,  h->qk,  h->pk,     h->gk,    h->Ck,       h->tC,    h->psi,  h->V,
                   h->rho,  h->plike, h->ioq, h->iop, h->gprior, h->glike, h->rho_part, h->partA, h->guard, h->stop,
-                  h->steps_done, h->hull};
+                  h->steps_done, h->hull, h->t_cnt, h->t_off, h->t_woff, h->t_rank, h->sx, h->sy, h->sz, h->sidx};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   for (int f = 0; f < 6; f++)

@@ -117,8 +117,12 @@ struct PosPar {
   int rsd, periodic;
 };
 
+// Compiled without FMA contraction: every kernel that calls this gets bit-identical positions (the sorted
+// path derives a particle's tile in one kernel and its LDS-local home cell in another), and the operation
+// sequence is the reference's (multiply, add, add, fmod) as its x86-64 build executes it.
 __device__ __forceinline__ void particle_pos(const PosPar &pp, int i, int j, int k, double psx, double psy,
                                              double psz, double &x, double &y, double &z) {
+#pragma clang fp contract(off)
   x = pp.d * (double)i + 0.5 * pp.d + psx;
   y = pp.d * (double)j + 0.5 * pp.d + psy;
   z = pp.d * (double)k + 0.5 * pp.d + psz;
@@ -152,7 +156,7 @@ __global__ void k_positions(Geo g, PosPar pp, const double *__restrict__ psi, do
 // decision, but rejects columns/cells on squared distance before paying for sqrt and the atomic.
 // ------------------------------------------------------------------------------------------------------
 struct SphPar {
-  double h, w_norm;  // kernel scale, 1/pi/h^3
+  double h, h_inv, w_norm;  // kernel scale, its inverse, 1/pi/h^3
   double r2_lim;     // 4 h^2 (1 + 1e-12): beyond this r/h <= 2 cannot hold
   double min1, min2, min3;
   int reach;
@@ -163,6 +167,39 @@ __device__ __forceinline__ double sph_w(double q, double w_norm) {
   if (q <= 1.) return w_norm * (1 - 3. / 2 * q * q + 3. / 4 * q * q * q);
   const double t = 2. - q;
   return w_norm * (1. / 4 * (t * t * t));
+}
+
+// 1/sqrt(x) to ~1 ulp: hardware v_rsq_f64 seed (>= 26 good bits) + two Newton steps (7 FMAs).  Replaces the
+// IEEE sqrt + divide pair of the reference's kernel evaluations (about 35 fp64 instructions with range
+// scaling and fix-ups); results differ from the correctly rounded ones by <= 2 ulp, far inside the stated
+// fp64 tolerance.  x must be positive and normal.
+__device__ __forceinline__ double fast_rsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  const double hx = 0.5 * x;
+  double e = fma(-hx * y, y, 0.5);
+  y = fma(y, e, y);
+  e = fma(-hx * y, y, 0.5);
+  y = fma(y, e, y);
+  return y;
+}
+
+// W_4 (massFunctions.cc:366-384), branch-free; valid for 0 <= q <= 2.
+__device__ __forceinline__ double sph_w_sel(double q, double w_norm) {
+  const double inner = fma(q * q, fma(0.75, q, -1.5), 1.);  // 1 - 3/2 q^2 + 3/4 q^3
+  const double t = 2. - q;
+  const double outer = 0.25 * (t * t * t);
+  return w_norm * ((q <= 1.) ? inner : outer);
+}
+
+// dW_4/dq / q in h units times `norm` (grad_SPH_kernel_3D_h_units, SPH_kernel.cpp:148-208), branch-free;
+// q_sq in (0, 4].  rq = 1/q.
+__device__ __forceinline__ double sph_grad_partial(double q_sq, double norm) {
+  const double rq = fast_rsqrt(fmax(q_sq, 1e-280));
+  const double q = q_sq * rq;
+  const double inner = (2.25 * q - 3.) * norm;
+  const double qm2 = q - 2.;
+  const double outer = (-0.75 * qm2 * qm2 * norm) * rq;
+  return (q_sq > 1.) ? outer : inner;
 }
 
 __global__ void __launch_bounds__(256)
@@ -541,6 +578,300 @@ k_grf_loglike(long long n, const double *__restrict__ q, const double *__restric
     }
   s = block_sum(s, red);
   if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+// ======================================================================================================
+// Tile-sorted particle-mesh path (the fast path for masskernel 3 when the tile shape divides the grid).
+//
+// Zel'dovich displacements at the BASELINE resolution are many cells long (rms 3-10 cells at 256^3 in a
+// 200 Mpc/h box), so a Lagrangian brick of particles does NOT stay inside an LDS-sized Eulerian tile.  We
+// therefore bin the particles by the Eulerian tile of their home cell every force evaluation (counting
+// sort: one returning int atomic per particle, one scan, one reorder pass), and then
+//   * scatter: one workgroup per (tile, chunk of <= `chunk` particles) accumulates W into an LDS copy of the
+//     tile plus a halo of `R` cells with LDS fp64 atomics and flushes its non-zero cells to HBM once
+//     (a few coalesced global atomics per cell instead of ~34 scattered ones per particle);
+//   * gather: the same work items stage part_like (tile + halo) in LDS and each particle reads its 81
+//     stencil cells from there.
+// Arithmetic per (particle, cell) pair is identical to the direct kernels above, which stay as the fallback.
+// ======================================================================================================
+struct TilePar {
+  int tx, ty, tz;     // tile shape in cells (z fastest)
+  int ntx, nty, ntz;  // tiles per axis
+  int ntiles;
+  int R;              // halo = stencil reach
+  int lx, ly, lz;     // LDS tile shape = t + 2R
+  int chunk;          // max particles per work item
+};
+
+constexpr int kSortFlagNoScatter = 1 << 30;  // record flag: particle fails getDensity_SPH's domain test
+
+__device__ __forceinline__ int tile_of(const TilePar &tp, int n, long long ix, long long iy, long long iz) {
+  const int cx = (int)(ix % n), cy = (int)(iy % n), cz = (int)(iz % n);
+  return (cz / tp.tz) + tp.ntz * ((cy / tp.ty) + tp.nty * (cx / tp.tx));
+}
+
+// Workgroup -> particles.  When 16 divides n a workgroup takes a 4 x 4 x 16 brick of the Lagrangian lattice
+// (neighbours in space: few distinct tiles per workgroup, 128-byte rows of psi); otherwise 256 consecutive ones.
+__device__ __forceinline__ long long brick_particle(const Geo &g, int &i, int &j, int &k) {
+  const int n = g.n, tid = threadIdx.x;
+  if ((n & 15) == 0) {
+    const int nbz = n >> 4, nby = n >> 2;
+    const int b = blockIdx.x;
+    const int bk = b % nbz, bj = (b / nbz) % nby, bi = b / (nbz * nby);
+    i = bi * 4 + (tid >> 6);
+    j = bj * 4 + ((tid >> 4) & 3);
+    k = bk * 16 + (tid & 15);
+    return k + (long long)n * (j + (long long)n * i);
+  }
+  const long long p = blockIdx.x * (long long)blockDim.x + tid;
+  k = (int)(p % n);
+  const long long ij = p / n;
+  j = (int)(ij % n);
+  i = (int)(ij / n);
+  return p;
+}
+
+// Pass 1: tile id and arrival rank of every particle.  The workgroup first counts its particles per tile in
+// an LDS hash table, then reserves one contiguous rank range per distinct tile with a single global atomic
+// (a handful per workgroup instead of one returning atomic per particle on ~n^3/2048 hot counters).
+// Particles with a non-finite position are left out (tile -1); the gather gives them V = 0.
+__global__ void __launch_bounds__(256)
+k_bin(Geo g, PosPar pp, SphPar sp, TilePar tp, const double *__restrict__ psi, int *__restrict__ cnt,
+      int2 *__restrict__ tile_rank, double *__restrict__ V) {
+  constexpr int kSlots = 512;
+  __shared__ int hkey[kSlots], hcnt[kSlots], hbase[kSlots];
+  for (int s = threadIdx.x; s < kSlots; s += blockDim.x) {
+    hkey[s] = 0;
+    hcnt[s] = 0;
+  }
+  __syncthreads();
+  int i, j, k;
+  const long long p = brick_particle(g, i, j, k);
+  const bool live = p < g.N;
+  int t = -1, slot = 0, local = 0, flag = 0;
+  if (live) {
+    double x, y, z;
+    particle_pos(pp, i, j, k, psi[p], psi[p + g.N], psi[p + 2 * g.N], x, y, z);
+    if (x >= 0. && x <= g.L && y >= 0. && y <= g.L && z >= 0. && z <= g.L) {
+      t = tile_of(tp, g.n, (long long)(x / g.d), (long long)(y / g.d), (long long)(z / g.d));
+      const bool in_domain = (x >= sp.min1 && x < sp.min1 + g.L) && (y >= sp.min2 && y < sp.min2 + g.L) &&
+                             (z >= sp.min3 && z < sp.min3 + g.L);  // massFunctions.cc:426
+      flag = in_domain ? 0 : kSortFlagNoScatter;
+      slot = (int)(((unsigned)t * 2654435761u) >> 23) & (kSlots - 1);
+      for (;;) {
+        const int old = atomicCAS(&hkey[slot], 0, t + 1);
+        if (old == 0 || old == t + 1) break;
+        slot = (slot + 1) & (kSlots - 1);
+      }
+      local = atomicAdd(&hcnt[slot], 1);
+    } else {
+      V[p] = 0.;
+      V[p + g.N] = 0.;
+      V[p + 2 * g.N] = 0.;
+    }
+  }
+  __syncthreads();
+  for (int s = threadIdx.x; s < kSlots; s += blockDim.x)
+    if (hkey[s]) hbase[s] = atomicAdd(&cnt[hkey[s] - 1], hcnt[s]);
+  __syncthreads();
+  if (live) tile_rank[p] = (t < 0) ? make_int2(-1, 0) : make_int2(t, (hbase[slot] + local) | flag);
+}
+
+// Pass 2 (one workgroup): exclusive scans of the tile counts (-> record offsets) and of the per-tile chunk
+// counts (-> work-item offsets).  off and woff have ntiles + 1 entries.
+__global__ void __launch_bounds__(1024)
+k_scan_tiles(TilePar tp, const int *__restrict__ cnt, int *__restrict__ off, int *__restrict__ woff) {
+  __shared__ int sa[1024], sb[1024];
+  const int T = tp.ntiles, tid = threadIdx.x;
+  const int per = (T + 1023) / 1024;
+  const int lo = min(tid * per, T), hi = min(lo + per, T);
+  int a = 0, b = 0;
+  for (int t = lo; t < hi; t++) {
+    a += cnt[t];
+    b += (cnt[t] + tp.chunk - 1) / tp.chunk;
+  }
+  sa[tid] = a;
+  sb[tid] = b;
+  __syncthreads();
+  for (int s = 1; s < 1024; s <<= 1) {
+    const int va = tid >= s ? sa[tid - s] : 0, vb = tid >= s ? sb[tid - s] : 0;
+    __syncthreads();
+    sa[tid] += va;
+    sb[tid] += vb;
+    __syncthreads();
+  }
+  int ea = sa[tid] - a, eb = sb[tid] - b;  // exclusive prefixes of this thread's segment
+  for (int t = lo; t < hi; t++) {
+    off[t] = ea;
+    woff[t] = eb;
+    ea += cnt[t];
+    eb += (cnt[t] + tp.chunk - 1) / tp.chunk;
+  }
+  if (tid == 1023) {
+    off[T] = sa[1023];
+    woff[T] = sb[1023];
+  }
+}
+
+// Pass 3: write each particle's record (position, original index | flag) to its sorted slot.
+__global__ void __launch_bounds__(256)
+k_reorder(Geo g, PosPar pp, const double *__restrict__ psi, const int2 *__restrict__ tile_rank,
+          const int *__restrict__ off, double *__restrict__ sx, double *__restrict__ sy, double *__restrict__ sz,
+          int *__restrict__ sidx) {
+  int i, j, k;
+  const long long p = brick_particle(g, i, j, k);
+  if (p >= g.N) return;
+  const int2 tr = tile_rank[p];
+  if (tr.x < 0) return;
+  double x, y, z;
+  particle_pos(pp, i, j, k, psi[p], psi[p + g.N], psi[p + 2 * g.N], x, y, z);
+  const int slot = off[tr.x] + (tr.y & ~kSortFlagNoScatter);
+  sx[slot] = x;
+  sy[slot] = y;
+  sz[slot] = z;
+  sidx[slot] = (int)p | (tr.y & kSortFlagNoScatter);
+}
+
+// Work item -> (tile, particle range).  Returns false when this workgroup has nothing to do.
+__device__ __forceinline__ bool tile_work(const TilePar &tp, const int *__restrict__ off, const int *__restrict__ woff,
+                                          int &tile, int &p_begin, int &p_end) {
+  __shared__ int s_tile, s_b, s_e;
+  if (threadIdx.x == 0) {
+    const int w = blockIdx.x;
+    int t = -1, b = 0, e = 0;
+    if (w < woff[tp.ntiles]) {
+      int lo = 0, hi = tp.ntiles;  // last t with woff[t] <= w
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (woff[mid] <= w) lo = mid; else hi = mid;
+      }
+      t = lo;
+      b = off[t] + (w - woff[t]) * tp.chunk;
+      e = min(b + tp.chunk, off[t + 1]);
+    }
+    s_tile = t;
+    s_b = b;
+    s_e = e;
+  }
+  __syncthreads();
+  tile = s_tile;
+  p_begin = s_b;
+  p_end = s_e;
+  return tile >= 0;
+}
+
+// getDensity_SPH on sorted particles: LDS accumulation per (tile, chunk), one flush.
+__global__ void __launch_bounds__(256)
+k_scatter_tile(Geo g, SphPar sp, TilePar tp, const double *__restrict__ sx, const double *__restrict__ sy,
+               const double *__restrict__ sz, const int *__restrict__ sidx, const int *__restrict__ off,
+               const int *__restrict__ woff, double *__restrict__ rho) {
+  extern __shared__ double s_tile_acc[];
+  int tile, pb, pe;
+  if (!tile_work(tp, off, woff, tile, pb, pe)) return;
+  const int ncell = tp.lx * tp.ly * tp.lz;
+  for (int c = threadIdx.x; c < ncell; c += blockDim.x) s_tile_acc[c] = 0.;
+  __syncthreads();
+  const int tzi = tile % tp.ntz, tyi = (tile / tp.ntz) % tp.nty, txi = tile / (tp.ntz * tp.nty);
+  const int ox = txi * tp.tx - tp.R, oy = tyi * tp.ty - tp.R, oz = tzi * tp.tz - tp.R;  // global cell of LDS (0,0,0)
+  const int n = g.n, R = sp.reach;
+  const double d = g.d;
+  for (int s = pb + threadIdx.x; s < pe; s += blockDim.x) {
+    if (sidx[s] & kSortFlagNoScatter) continue;
+    const double x = sx[s], y = sy[s], z = sz[s];
+    const long long ix = (long long)(x / d), iy = (long long)(y / d), iz = (long long)(z / d);
+    const double ccx = ((double)ix + 0.5) * d, ccy = ((double)iy + 0.5) * d, ccz = ((double)iz + 0.5) * d;
+    const int hx = (int)(ix % n) - ox, hy = (int)(iy % n) - oy, hz = (int)(iz % n) - oz;  // home cell in LDS coords
+    if ((unsigned)(hx - tp.R) >= (unsigned)tp.tx || (unsigned)(hy - tp.R) >= (unsigned)tp.ty ||
+        (unsigned)(hz - tp.R) >= (unsigned)tp.tz)
+      continue;  // cannot happen (binning and this kernel see the same stored position); keeps LDS indexing safe
+    for (int i1 = -R; i1 <= R; ++i1) {
+      const double dx = x - (ccx + (double)i1 * d);
+      const double dx2 = dx * dx;
+      if (dx2 > sp.r2_lim) continue;
+      for (int i2 = -R; i2 <= R; ++i2) {
+        const double dy = y - (ccy + (double)i2 * d);
+        const double r2ab = dx2 + dy * dy;
+        if (r2ab > sp.r2_lim) continue;
+        double *row = s_tile_acc + tp.lz * ((hy + i2) + tp.ly * (hx + i1)) + hz;
+        for (int i3 = -R; i3 <= R; ++i3) {
+          const double dz = z - (ccz + (double)i3 * d);
+          const double r2 = r2ab + dz * dz;
+          if (r2 > sp.r2_lim) continue;
+          const double q = (r2 * fast_rsqrt(fmax(r2, 1e-280))) * sp.h_inv;
+          if (q <= 2.) atomic_add_f64(row + i3, sph_w_sel(q, sp.w_norm));
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < ncell; c += blockDim.x) {
+    const double v = s_tile_acc[c];
+    if (v != 0.) {
+      const int cz = c % tp.lz, cy = (c / tp.lz) % tp.ly, cx = c / (tp.lz * tp.ly);
+      const int gx = (ox + cx + n) % n, gy = (oy + cy + n) % n, gz = (oz + cz + n) % n;
+      atomic_add_f64(rho + gz + (long long)n * (gy + (long long)n * gx), v);
+    }
+  }
+}
+
+// likelihood_calc_V_SPH on sorted particles: part_like tile + halo staged in LDS.
+__global__ void __launch_bounds__(256)
+k_gather_tile(Geo g, HullPar hp, TilePar tp, int rsd, const double *__restrict__ sx, const double *__restrict__ sy,
+              const double *__restrict__ sz, const int *__restrict__ sidx, const int *__restrict__ off,
+              const int *__restrict__ woff, const double *__restrict__ plike, double *__restrict__ V) {
+  extern __shared__ double s_tile_pl[];
+  int tile, pb, pe;
+  if (!tile_work(tp, off, woff, tile, pb, pe)) return;
+  const int ncell = tp.lx * tp.ly * tp.lz;
+  int4 *s_cols = reinterpret_cast<int4 *>(s_tile_pl + ((ncell + 1) & ~1));
+  for (int m = threadIdx.x; m < hp.ncol; m += blockDim.x) s_cols[m] = hp.cols[m];
+  const int n = g.n;
+  const int tzi = tile % tp.ntz, tyi = (tile / tp.ntz) % tp.nty, txi = tile / (tp.ntz * tp.nty);
+  const int ox = txi * tp.tx - tp.R, oy = tyi * tp.ty - tp.R, oz = tzi * tp.tz - tp.R;
+  for (int c = threadIdx.x; c < ncell; c += blockDim.x) {
+    const int cz = c % tp.lz, cy = (c / tp.lz) % tp.ly, cx = c / (tp.lz * tp.ly);
+    const int gx = (ox + cx + n) % n, gy = (oy + cy + n) % n, gz = (oz + cz + n) % n;
+    s_tile_pl[c] = plike[gz + (long long)n * (gy + (long long)n * gx)];
+  }
+  __syncthreads();
+  const double d_h = hp.d_h;
+  for (int s = pb + threadIdx.x; s < pe; s += blockDim.x) {
+    const double px = sx[s], py = sy[s], pz = sz[s];
+    const int ix = (int)(px / g.d), iy = (int)(py / g.d), iz = (int)(pz / g.d);
+    const double dpcx = px * hp.h_inv - ((double)ix + 0.5) * d_h;
+    const double dpcy = py * hp.h_inv - ((double)iy + 0.5) * d_h;
+    const double dpcz = pz * hp.h_inv - ((double)iz + 0.5) * d_h;
+    const int hx = (ix % n) - ox, hy = (iy % n) - oy, hz = (iz % n) - oz;
+    double vx = 0., vy = 0., vz = 0.;
+    const bool home_ok = (unsigned)(hx - tp.R) < (unsigned)tp.tx && (unsigned)(hy - tp.R) < (unsigned)tp.ty &&
+                         (unsigned)(hz - tp.R) < (unsigned)tp.tz;  // always true; keeps LDS indexing safe
+    for (int m = 0; home_ok && m < hp.ncol; ++m) {
+      const int4 c = s_cols[m];
+      const double xh = dpcx - (double)c.x * d_h;
+      const double yh = dpcy - (double)c.y * d_h;
+      const double r2ab = xh * xh + yh * yh;
+      if (r2ab > 4.) continue;
+      const double *row = s_tile_pl + tp.lz * ((hy + c.y) + tp.ly * (hx + c.x)) + hz;
+      double zh = dpcz - (double)c.z * d_h;
+      for (int i3 = c.z; i3 <= c.w; ++i3) {
+        const double q_sq = r2ab + zh * zh;
+        const double partial = (q_sq <= 4.) ? sph_grad_partial(q_sq, hp.norm) : 0.;
+        const double common = row[i3] * partial;
+        vx += common * xh;
+        vy += common * yh;
+        vz += common * zh;
+        zh -= d_h;
+      }
+    }
+    vx *= hp.normalize;
+    vy *= hp.normalize;
+    vz *= hp.normalize;
+    if (rsd) vz += hp.f1 * vz;
+    const long long p = sidx[s] & ~kSortFlagNoScatter;
+    V[p] = vx;
+    V[p + g.N] = vy;
+    V[p + 2 * g.N] = vz;
+  }
 }
 
 }  // namespace bchmc

@@ -18,7 +18,7 @@ ABI_VERSION = 1
 FIELDS = dict(signal_PS=0, mass_f=1, mass_r=2, nobs=3, noise=4, window=5, deltaX=6, posx=7, posy=8, posz=9,
               rho=10, part_like=11, Vx=12, Vy=13, Vz=14, psix=15, psiy=16, psiz=17, grad_prior=18, grad_like=19)
 INPUT_FIELDS = ("signal_PS", "mass_f", "mass_r", "nobs", "noise", "window")
-K_COUNT = 8
+K_COUNT = 9
 
 
 class BchmcConfig(C.Structure):

@@ -135,7 +135,7 @@ void *bchmc_stream(bchmc_handle *h); /* hipStream_t the engine launches on */
 /* ---- measurement hooks (bench.py): per-kernel-class HIP-event timing on the engine's stream ---- */
 enum {
   BCHMC_K_FFT_C2R = 0, BCHMC_K_FFT_R2C, BCHMC_K_KSPACE_DRIFT_ZA, BCHMC_K_SCATTER, BCHMC_K_MEAN_PARTIAL,
-  BCHMC_K_GATHER, BCHMC_K_KSPACE_FORCE_KICK, BCHMC_K_OTHER, BCHMC_K_COUNT
+  BCHMC_K_GATHER, BCHMC_K_KSPACE_FORCE_KICK, BCHMC_K_SORT, BCHMC_K_OTHER, BCHMC_K_COUNT
 };
 int bchmc_profile(bchmc_handle *h, int enable);                 /* 1: record events around every launch */
 int bchmc_profile_read(bchmc_handle *h, double ms[BCHMC_K_COUNT], uint64_t launches[BCHMC_K_COUNT]); /* and reset */
