@@ -60,6 +60,8 @@ struct bchmc_handle {
   double *rho = nullptr, *plike = nullptr;              // N each
   double *ioq = nullptr, *iop = nullptr;                // N each: staging / scratch
   double *gprior = nullptr, *glike = nullptr;           // N each, lazily allocated by bchmc_gradient
+  double *conv = nullptr;                               // 3 N, lazily allocated for calc_h = 3
+  double *convF = nullptr;                              // Nh: SPH kernel transform table for calc_h = 3
   double *rho_part = nullptr, *partA = nullptr;         // kRedBlocks doubles each
   double *guard = nullptr;                              // guard slots, one per step
   size_t guard_cap = 0;
@@ -328,8 +330,11 @@ int forward_rest(bchmc_handle *h, int rsd) {
                                                     h->t_woff, h->rho);
     } else if (h->c.mk == 3) {
       k_scatter_sph<<<nblk_full(h->g.N), 256, 0, h->stream>>>(h->g, make_pos(h, rsd), make_sph(h), h->psi, h->rho);
+    } else if (h->c.mk >= 0 && h->c.mk <= 2) {
+      k_scatter_low_order<<<nblk_full(h->g.N), 256, 0, h->stream>>>(h->g, make_pos(h, rsd), make_sph(h), h->c.mk, h->psi,
+                                                                    h->rho);
     } else {
-      return h->fail(BCHMC_ERR_UNSUPPORTED, "masskernel %d not built yet (only 3 = SPH)", h->c.mk);
+      return h->fail(BCHMC_ERR_ARG, "masskernel %d is not a valid value (0..3)", h->c.mk);
     }
     HIPCHK(hipGetLastError());
   }
@@ -343,14 +348,44 @@ int forward_rest(bchmc_handle *h, int rsd) {
   return BCHMC_OK;
 }
 
+// Fourier transform of the SPH kernel on the half-complex grid (HMC_models_testing.cpp:96-111), host libm.
+int build_conv_table(bchmc_handle *h) {
+  const Geo &g = h->g;
+  const double hh = h->c.particle_kernel_h;
+  const double norm = (24. / (hh * hh * hh)) * (h->c.rho_c * g.L * g.L * g.L / (double)((size_t)g.n * g.n * g.n));
+  std::vector<double> F((size_t)g.Nh);
+  auto kv = [&](int i) { return (i <= g.n / 2) ? g.kfac * (double)i : -g.kfac * (double)(g.n - i); };
+  for (int i = 0; i < g.n; ++i) {
+    const double kx = kv(i);
+    for (int j = 0; j < g.n; ++j) {
+      const double ky = kv(j);
+      for (int k = 0; k < g.nh; ++k) {
+        const double kz = kv(k);
+        const double k_sq = kx * kx + ky * ky + kz * kz;
+        double f;
+        if (k_sq == 0.) {
+          f = 1. / (hh * hh * hh);
+        } else {
+          const double kk = std::sqrt(k_sq);
+          const double ksink = kk * std::sin(kk);
+          f = norm * (3 + std::cos(2 * kk) - ksink + std::cos(kk) * (ksink - 4)) / (k_sq * k_sq * k_sq);
+        }
+        F[k + (size_t)g.nh * (j + (size_t)g.n * i)] = f;
+      }
+    }
+  }
+  CHK(dev_alloc(h, &h->convF, (size_t)g.Nh));
+  HIPCHK(hipMemcpy(h->convF, F.data(), F.size() * sizeof(double), hipMemcpyHostToDevice));
+  return BCHMC_OK;
+}
+
 // After forward_rest: leaves the k-space likelihood source in Ck and returns the assemble mode.
 int like_force(bchmc_handle *h, int *like_mode) {
   if (h->c.calc_h == 2 || h->c.calc_h == 3) {
     if (h->c.mk != 3)
       return h->fail(BCHMC_ERR_MK_NOT_SPH, "Must use SPH mass kernel (masskernel = 3) with calc_h = 2 or 3");
-    if (h->c.calc_h == 3) return h->fail(BCHMC_ERR_UNSUPPORTED, "calc_h = 3 (Fourier/TSC) not built yet");
-  } else if (h->c.calc_h != 1) {
-    return h->fail(BCHMC_ERR_UNSUPPORTED, "calc_h = %d not supported (use 1, 2 or 3)", h->c.calc_h);
+  } else if (h->c.calc_h != 1 && h->c.calc_h != 0) {
+    return h->fail(BCHMC_ERR_ARG, "calc_h = %d is not a valid value (0..3)", h->c.calc_h);
   }
   {
     ProfScope ps(h, BCHMC_K_MEAN_PARTIAL);
@@ -364,7 +399,55 @@ int like_force(bchmc_handle *h, int *like_mode) {
     *like_mode = 1;
     return BCHMC_OK;
   }
-  {
+  if (h->c.calc_h == 0) {
+    // likelihood_calc_h (HMC_models_testing.cpp:25-50)
+    {
+      ProfScope ps(h, BCHMC_K_OTHER);
+      k_overdens<<<nblk_stride(h->g.N), 256, 0, h->stream>>>(h->g, h->rho, h->rho_part, h->ioq);
+      HIPCHK(hipGetLastError());
+    }
+    if (h->c.likelihood == 1) {
+      if (!h->conv) CHK(dev_alloc(h, &h->conv, 3 * (size_t)h->g.N));
+      CHK(fft_exec(h, h->r2c1, h->ioq, h->tC, BCHMC_K_FFT_R2C));
+      {
+        ProfScope ps(h, BCHMC_K_OTHER);
+        k_gradfft_mult<<<nblk_stride(h->g.Nh), 256, 0, h->stream>>>(h->g, h->tC, h->Ck, 1. / (double)h->g.N);
+        HIPCHK(hipGetLastError());
+      }
+      CHK(fft_exec(h, h->c2r3, h->Ck, h->conv, BCHMC_K_FFT_C2R));
+      ProfScope ps(h, BCHMC_K_OTHER);
+      k_mul3<<<nblk_stride(h->g.N), 256, 0, h->stream>>>(h->g.N, h->plike, h->conv, h->V);
+      HIPCHK(hipGetLastError());
+    } else {
+      ProfScope ps(h, BCHMC_K_OTHER);
+      k_findif_mul<<<nblk_stride(h->g.N), 256, 0, h->stream>>>(h->g, make_like(h), h->ioq, h->plike, h->V);
+      HIPCHK(hipGetLastError());
+    }
+    CHK(fft_exec(h, h->r2c3, h->V, h->Ck, BCHMC_K_FFT_R2C));
+    *like_mode = 0;
+    return BCHMC_OK;
+  }
+  if (h->c.calc_h == 3) {
+    // likelihood_calc_V_SPH_fourier_TSC (HMC_models_testing.cpp:54-188)
+    if (h->last_rsd && !h->c.planepar)
+      return h->fail(BCHMC_ERR_RSD_NOT_PLANEPAR, "non-plane-parallel RSD is not implemented in calc_V");
+    if (!h->conv) CHK(dev_alloc(h, &h->conv, 3 * (size_t)h->g.N));
+    if (!h->convF) CHK(build_conv_table(h));
+    CHK(fft_exec(h, h->r2c1, h->plike, h->tC, BCHMC_K_FFT_R2C));
+    const double hh = h->c.particle_kernel_h;
+    {
+      ProfScope ps(h, BCHMC_K_OTHER);
+      k_conv_kernel<<<nblk_stride(h->g.Nh), 256, 0, h->stream>>>(h->g, h->tC, h->convF, h->Ck, hh, 1. / (double)h->g.N);
+      HIPCHK(hipGetLastError());
+    }
+    CHK(fft_exec(h, h->c2r3, h->Ck, h->conv, BCHMC_K_FFT_C2R));
+    {
+      ProfScope ps(h, BCHMC_K_GATHER);
+      k_interp_tsc<<<nblk_full(h->g.N), 256, 0, h->stream>>>(h->g, make_pos(h, h->last_rsd),
+                                                             fgrow1(h->c.ascale, h->c.OM, h->c.OL), h->psi, h->conv, h->V);
+      HIPCHK(hipGetLastError());
+    }
+  } else {
     ProfScope ps(h, BCHMC_K_GATHER);
     HullPar hp = make_hull(h);
     if (h->tiled && h->sorted_valid) {
@@ -754,7 +837,7 @@ void bchmc_destroy(bchmc_handle *h) {
   if (h->info) rocfft_execution_info_destroy(h->info);
   void *ptrs[] = {h->work, h->wS,  h->wM,  h->qk,  h->pk,     h->gk,    h->Ck,       h->tC,    h->psi,  h->V,
                   h->rho,  h->plike, h->ioq, h->iop, h->gprior, h->glike, h->rho_part, h->partA, h->guard, h->stop,
-                  h->steps_done, h->hull, h->t_cnt, h->t_off, h->t_woff, h->t_rank, h->sx, h->sy, h->sz, h->sidx};
+                  h->steps_done, h->hull, h->conv, h->convF, h->t_cnt, h->t_off, h->t_woff, h->t_rank, h->sx, h->sy, h->sz, h->sidx};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   for (int f = 0; f < 6; f++)

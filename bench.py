@@ -35,7 +35,28 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-nx", type=int, default=0, help="grid of the CPU-baseline sample (default: same as --nx)")
     ap.add_argument("--no-kernel-profile", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="process-group backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--single-device", action="store_true",
+                    help="rehearsal only: every rank uses cuda:0 (never for reported numbers)")
     return ap.parse_args()
+
+
+def pmc_traffic(nx):
+    """HBM bytes per leapfrog step from the newest committed rocprofv3 PMC summary (profiles/r*_pmc_traffic.json,
+    made by scripts/pmc_traffic.py from separate FETCH_SIZE / WRITE_SIZE passes of this bench command).
+    Returns None when no summary exists for this grid."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json"))):
+        try:
+            d = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if d.get("grid", 256) == nx:
+            best = (path, d)
+    if best is None:
+        return None, None
+    return best[1]["hbm_bytes_per_step"], os.path.relpath(best[0], ROOT)
 
 
 def cpu_baseline(params, case_arrays, q0, p0, eps):
@@ -76,9 +97,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
     if distributed:
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
     if args.gpus != world and rank == 0:
         print("bench.py: --gpus %d but WORLD_SIZE %d; running %d rank(s)" % (args.gpus, world, world), file=sys.stderr)
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -91,7 +114,7 @@ def main():
     # BASELINE config 3: "256^3, 2LPT + RSD": under rsd_model the reference dispatches to Zel'dovich + plane-parallel
     # RSD whatever sfmodel says; Gaussian likelihood, SPH kernel, calc_h 2, mass_type 1, fp64.
     params = HamilParams(Nx=args.nx, L=200.0, likelihood=args.likelihood, rsd_model=rsd, sfmodel=2 if rsd else 1)
-    group = ChainGroup(pool=True, device=dev)
+    group = ChainGroup(pool=True, device=dev if args.backend == "nccl" else torch.device("cpu"))
     ring = EpsRing()
 
     f = inputs.make_fields(params)
@@ -141,7 +164,7 @@ def main():
     wall = t1 - t0
     gpu_ms = ev0.elapsed_time(ev1)
     if distributed:
-        t = torch.tensor([wall], dtype=torch.float64, device=dev)
+        t = torch.tensor([wall], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
     if done != args.steps:
@@ -165,6 +188,7 @@ def main():
         steps_total = args.steps * world
         value = steps_total / wall
         achieved = ALGO_BYTES_PER_CELL_STEP * N * args.steps / (gpu_ms * 1e-3) / 1e9  # per GPU, device time
+        traffic, traffic_src = pmc_traffic(params.Nx) if (rsd and params.likelihood == 1) else (None, None)
         out = {
             "metric": "HMC leapfrog steps/sec on %d^3 grid" % params.Nx,
             "value": round(value, 4),
@@ -184,6 +208,7 @@ def main():
                             "trajectory of %d leapfrog steps per chain" % (params.Nx, " + plane-parallel RSD" if rsd else "",
                                                                            params.likelihood, args.steps),
                 "grid": params.Nx, "chains": world, "parallelism": "independent chains, 1 per GPU",
+                "rehearsal_single_device": bool(args.single_device),
                 "eps": eps, "steps_done": int(done), "finite": finite,
             },
             "roofline": {
@@ -193,7 +218,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": traffic_src,
                 "algorithmic_bytes_per_step": ALGO_BYTES_PER_CELL_STEP * N,
                 "device_ms_per_step": round(gpu_ms / args.steps, 4),
                 "kernels": kernels,

@@ -33,7 +33,7 @@ typedef struct bchmc_config {
   double xobs, yobs, zobs;
   int32_t planepar, periodic;
   int32_t mk;                /* masskernel: 0 NGP, 1 CIC, 2 TSC, 3 SPH */
-  int32_t calc_h;            /* 1, 2 (SPH adjoint, default) or 3 (Fourier + TSC) */
+  int32_t calc_h;            /* 0 (legacy), 1, 2 (SPH adjoint, default) or 3 (Fourier + TSC) */
   int32_t likelihood;        /* 0 Poisson, 1 Gaussian, 2 log-normal, 3 GRF (init_par.cc:534-559) */
   int32_t sfmodel;           /* 1 Zel'dovich (others only together with rsd_model) */
   int32_t rsd_model;

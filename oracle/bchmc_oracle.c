@@ -874,6 +874,95 @@ static void add_to_array(const double *in, double *out, size_t n) {
   for (long i = 0; i < (long)n; i++) out[i] += in[i];
 }
 
+
+/* gradient.cpp:22-78: spectral gradient i k_dim f^, Nyquist planes zeroed (unplanned FFTs, fftwrapper.cc:26-79) */
+static void gradfft(orc_hamil *h, const double *in, double *out, unsigned dim) {
+  const unsigned N1 = h->N1, N2 = h->N2, N3 = h->N3, N3half = N3 / 2 + 1;
+  double *AUX = dalloc(2 * h->Nhalf);
+  orc_fft_r2c_3d(N1, N2, N3, in, AUX);
+#pragma omp parallel for
+  for (long i = 0; i < (long)N1; i++)
+    for (unsigned j = 0; j < N2; j++)
+      for (unsigned k = 0; k < N3half; ++k) {
+        double kl = dim == 1 ? calc_ki((unsigned)i, h->L1, N1) : (dim == 2 ? calc_ki(j, h->L2, N2) : calc_ki(k, h->L3, N3));
+        size_t ll = k + (size_t)N3half * (j + (size_t)N2 * i);
+        double dummy = AUX[2 * ll];
+        AUX[2 * ll] = -kl * AUX[2 * ll + 1];
+        AUX[2 * ll + 1] = kl * dummy;
+        if (((unsigned)i == N1 / 2) || (j == N2 / 2) || (k == N3 / 2)) {
+          AUX[2 * ll] = 0.;
+          AUX[2 * ll + 1] = 0.;
+        }
+      }
+  orc_fft_c2r_3d(N1, N2, N3, AUX, out);
+  multiply_factor_array(1 / (double)h->N, out, out, h->N);
+  free(AUX);
+}
+
+/* gradient.cpp:81-154: 4th-order central differences, periodic */
+static void gradfindif(orc_hamil *h, const double *in, double *out, unsigned dim) {
+  const int N1 = (int)h->N1;
+  const double fac = N1 / (2. * h->L1);
+#pragma omp parallel for
+  for (long x = 0; x < N1; x++)
+    for (int y = 0; y < N1; y++)
+      for (int z = 0; z < N1; z++) {
+        int c[3] = {(int)x, y, z};
+        int l[3] = {c[0], c[1], c[2]}, ll[3] = {c[0], c[1], c[2]}, r[3] = {c[0], c[1], c[2]}, rr[3] = {c[0], c[1], c[2]};
+        const int a = (int)dim - 1;
+        r[a] = c[a] + 1; l[a] = c[a] - 1; rr[a] = c[a] + 2; ll[a] = c[a] - 2;
+        if (r[a] >= N1) r[a] -= N1;
+        if (rr[a] >= N1) rr[a] -= N1;
+        if (l[a] < 0) l[a] += N1;
+        if (ll[a] < 0) ll[a] += N1;
+#define IX(v) ((size_t)(v)[2] + (size_t)N1 * ((size_t)(v)[1] + (size_t)N1 * (size_t)(v)[0]))
+        out[IX(c)] = -(fac * ((4.0 / 3) * (in[IX(l)] - in[IX(r)]) - (1.0 / 6) * (in[IX(ll)] - in[IX(rr)])));
+#undef IX
+      }
+}
+
+/* *_likelihood_grad_f_delta_x_comp: gaussian_independent.cpp:43-50 (gradfft), poissonian.cpp:37-42 (gradfindif),
+ * lognormal_independent.cpp:71-91 (gradfindif of log(rho_c (1 + max(delta, delta_min)))) */
+static int grad_f_delta_x_comp(orc_hamil *h, const double *deltaX, double *out, unsigned comp) {
+  switch (h->c.likelihood) {
+    case 1: gradfft(h, deltaX, out, comp); return ORC_OK;
+    case 0: gradfindif(h, deltaX, out, comp); return ORC_OK;
+    case 2: {
+      double *f = dalloc(h->N);
+      for (size_t i = 0; i < h->N; i++) {
+        double d = deltaX[i];
+        if (d < h->c.delta_min) d = h->c.delta_min;
+        f[i] = log(h->c.rho_c * (1. + d));
+      }
+      gradfindif(h, f, out, comp);
+      free(f);
+      return ORC_OK;
+    }
+  }
+  return ORC_ERR_UNSUPPORTED;
+}
+
+/* HMC_models_testing.cpp:25-50 (calc_h = 0, labelled WRONG upstream but still selectable) */
+static int likelihood_calc_h(orc_hamil *h, const double *deltaX, double *out) {
+  double *partLike = dalloc(h->N), *dummy = dalloc(h->N);
+  double *outC = dalloc(2 * h->Nhalf), *dummyC = dalloc(2 * h->Nhalf);
+  int rc = orc_partial_f_delta_x_log_like(h, deltaX, partLike);
+  for (unsigned i = 1; i <= 3 && rc == ORC_OK; i++) {
+    rc = grad_f_delta_x_comp(h, deltaX, dummy, i);
+    if (rc != ORC_OK) break;
+    for (size_t m = 0; m < h->N; m++) dummy[m] = partLike[m] * dummy[m];
+    orc_fft_r2c_3d(h->N1, h->N2, h->N3, dummy, dummyC);
+    grad_inv_lap_FS(h, dummyC, i);
+    add_to_array(dummyC, outC, 2 * h->Nhalf);
+  }
+  if (rc == ORC_OK) {
+    orc_fft_c2r_3d(h->N1, h->N2, h->N3, outC, out);
+    multiply_factor_array(1 / (double)h->N, out, out, h->N);
+  }
+  free(partLike); free(dummy); free(outC); free(dummyC);
+  return rc;
+}
+
 /* a12: HMC_models.cc:312-372 */
 int orc_likelihood_calc_h_SPH(orc_hamil *h, const double *deltaX, double *out) {
   if (!(h->c.mk == 3)) return ORC_ERR_MK_NOT_SPH;
@@ -918,7 +1007,12 @@ int orc_likelihood_grad_log_like(orc_hamil *h, const double *delta, double *out)
                    h->c.rsd_model);
   if (rc != ORC_OK) return rc;
   switch (h->c.calc_h) {
-    case 0: return ORC_ERR_UNSUPPORTED; /* likelihood_calc_h (HMC_models_testing.cpp:25-50): labelled WRONG upstream */
+    case 0: {
+      double *tmp = dalloc(h->N); /* the reference writes into C2Rplan->R while the FFTs inside use their own buffers */
+      rc = likelihood_calc_h(h, A(h, ORC_F_DELTAX), tmp);
+      copyArray(tmp, h->C2R_R, h->N);
+      free(tmp);
+    } break;
     case 1: rc = orc_partial_f_delta_x_log_like(h, A(h, ORC_F_DELTAX), h->C2R_R); break;
     case 2:
     case 3: rc = orc_likelihood_calc_h_SPH(h, A(h, ORC_F_DELTAX), h->C2R_R); break;

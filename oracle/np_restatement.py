@@ -162,13 +162,30 @@ class NpHamil:
         hk = sum(-1j * self.r2c(v) * k * inv for v, k in zip(V, (self.kx, self.ky, self.kz)))
         return self.c2r(hk)
 
+    # HMC_models_testing.cpp:25-50 with gradfft (gradient.cpp:22-78) / gradfindif (gradient.cpp:81-154)
+    def calc_h_legacy(self, dX):
+        p = self.p
+        part = self.partial_f(dX)
+        if p.likelihood == 1:
+            fk = self.r2c(dX)
+            grads = [self.c2r(np.where(self.nyq, 0.0, 1j * k * fk)) for k in (self.kx, self.ky, self.kz)]
+        else:
+            f = dX if p.likelihood == 0 else np.log(p.rho_c * (1 + np.maximum(dX, p.delta_min)))
+            fac = self.n / (2.0 * self.L)
+            grads = [-(fac * ((4.0 / 3) * (np.roll(f, 1, a) - np.roll(f, -1, a))
+                              - (1.0 / 6) * (np.roll(f, 2, a) - np.roll(f, -2, a)))) for a in range(3)]
+        return self.calc_h([part * g for g in grads])
+
     # HMC_models.cc:377-471
     def grad_log_like(self, q):
         p = self.p
         rsd = bool(p.rsd_model)
         dX, pos = self.lag2eul(p.deltaQ_factor * q.reshape(self.shape), rsd)
         self.deltaX, self.pos = dX, pos
-        hfield = self.calc_h(self.calc_V(self.partial_f(dX), pos, rsd))
+        if p.calc_h == 0:
+            hfield = self.calc_h_legacy(dX)
+        else:
+            hfield = self.calc_h(self.calc_V(self.partial_f(dX), pos, rsd))
         norm = -1.0 * p.deltaQ_factor * (p.D1 if p.correct_delta else 1.0)
         return norm * hfield
 

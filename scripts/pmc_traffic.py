@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Turn two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs of the same bench command) into
+HBM bytes per leapfrog step, per kernel and in total.
+
+    python scripts/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <steps> [out.json]
+
+Counter units and gfx950 corrections follow /opt/skills/guides/MI355X_MICROARCH.md section HBM:
+  * FETCH_SIZE / WRITE_SIZE are in KiB (bytes = value * 1024);
+  * on gfx950 FETCH_SIZE reports exactly 1/2 of the bytes of a wide coalesced streaming read -> doubled here;
+    WRITE_SIZE reads exactly for streaming stores and float atomics.
+The doubling is calibrated for 16 B/lane streaming reads; our k-space kernels (double2 per lane) match that
+pattern, 8 B/lane kernels are cross-checked against their known byte counts in the printed table.
+Only the dispatches of the timed trajectory's step loop are counted: from the first k_kick_drift_za<true>
+after the last k_init_ctl up to the last k_assemble<true>.
+"""
+import csv
+import json
+import re
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    name = re.sub(r"^void ", "", name)
+    m = re.match(r"(bchmc::)?([A-Za-z0-9_]+(<[a-z]+>)?)", name)
+    return m.group(2) if m else name[:40]
+
+
+def load(path, counter):
+    rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter]
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    names = [short(r["Kernel_Name"]) for r in rows]
+    start = max(i for i, n in enumerate(names) if n == "k_init_ctl")
+    first = next(i for i in range(start, len(names)) if names[i] == "k_kick_drift_za<true>")
+    last = max(i for i, n in enumerate(names) if n == "k_assemble<true>")
+    per = defaultdict(lambda: [0.0, 0])
+    for r, n in zip(rows[first:last + 1], names[first:last + 1]):
+        per[n][0] += float(r["Counter_Value"]) * 1024.0
+        per[n][1] += 1
+    return per
+
+
+def main():
+    fetch_csv, write_csv, steps = sys.argv[1], sys.argv[2], int(sys.argv[3])
+    fetch, write = load(fetch_csv, "FETCH_SIZE"), load(write_csv, "WRITE_SIZE")
+    kernels = {}
+    tot_r = tot_w = 0.0
+    for n in sorted(set(fetch) | set(write)):
+        r = 2.0 * fetch[n][0] / steps  # gfx950: FETCH_SIZE counts half the streamed bytes
+        w = write[n][0] / steps
+        calls = max(fetch[n][1], write[n][1]) / steps
+        kernels[n] = dict(read_MB_per_step=round(r / 1e6, 1), write_MB_per_step=round(w / 1e6, 1),
+                          launches_per_step=round(calls, 2))
+        tot_r += r
+        tot_w += w
+    out = dict(steps=steps, hbm_read_bytes_per_step=tot_r, hbm_write_bytes_per_step=tot_w,
+               hbm_bytes_per_step=tot_r + tot_w, fetch_size_correction=2.0, kernels=kernels)
+    print("%-34s %10s %10s %8s" % ("kernel", "read MB", "write MB", "launches"))
+    for n, k in kernels.items():
+        print("%-34s %10.1f %10.1f %8.2f" % (n, k["read_MB_per_step"], k["write_MB_per_step"], k["launches_per_step"]))
+    print("total per step: read %.1f MB, write %.1f MB, sum %.3f GB" % (tot_r / 1e6, tot_w / 1e6, (tot_r + tot_w) / 1e9))
+    if len(sys.argv) > 4:
+        json.dump(out, open(sys.argv[4], "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -29,6 +29,8 @@ CASES = {
     "lognormal_zeld_8": dict(Nx=8, likelihood=2, rsd_model=0),
     "grf_8": dict(Nx=8, likelihood=3, rsd_model=0),
     "gauss_mass5_8": dict(Nx=8, likelihood=1, rsd_model=0, mass_type=5),
+    "gauss_calch3_rsd_8": dict(Nx=8, likelihood=1, rsd_model=1, calc_h=3),
+    "gauss_cic_calch1_8": dict(Nx=8, likelihood=1, rsd_model=0, calc_h=1, mk=1),
 }
 NEPS = 10
 
@@ -48,6 +50,9 @@ def make(name, kw):
         out.update(deltaX=dX, posx=pos[0], posy=pos[1], posz=pos[2], part_like=pl)
         if c.p.calc_h == 2:
             V = o.likelihood_calc_V_SPH(pl, *pos)
+            out.update(Vx=V[0], Vy=V[1], Vz=V[2])
+        elif c.p.calc_h == 3:
+            V = o.likelihood_calc_V_SPH_fourier_TSC(pl, *pos)
             out.update(Vx=V[0], Vy=V[1], Vz=V[2])
     q1, p1, done = o.Hamiltonian_EoM(c.q0, c.p0, c.eps, NEPS)
     dH, terms = o.delta_Hamiltonian(c.q0, c.p0, q1, p1)

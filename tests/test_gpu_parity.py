@@ -21,6 +21,14 @@ CONFIGS = [
     dict(likelihood=1, rsd_model=0, mass_type=0),          # real-space mass only
     dict(likelihood=1, rsd_model=0, mass_type=5),          # Fourier + real-space mass
     dict(likelihood=1, rsd_model=0, calc_h=1),             # h = partial_f (HMC_models.cc:413-415)
+    dict(likelihood=1, rsd_model=0, calc_h=0),             # legacy likelihood_calc_h, spectral gradient
+    dict(likelihood=0, rsd_model=0, calc_h=0, mk=1),       # legacy, finite differences, CIC
+    dict(likelihood=2, rsd_model=0, calc_h=0, eps_scale=1e-3),  # legacy, finite differences of log density (stiff)
+    dict(likelihood=1, rsd_model=0, calc_h=3),             # Fourier + TSC variant of V (HMC_models_testing.cpp:54-188)
+    dict(likelihood=1, rsd_model=1, calc_h=3, sfmodel=2),
+    dict(likelihood=1, rsd_model=0, calc_h=1, mk=1),       # CIC forward model (massFunctions.cc:100-164)
+    dict(likelihood=0, rsd_model=0, calc_h=1, mk=0),       # NGP (massFunctions.cc:49-98)
+    dict(likelihood=1, rsd_model=1, calc_h=1, mk=2),       # TSC (massFunctions.cc:167-364)
     dict(likelihood=1, rsd_model=1, deltaQ_factor=0.9, grad_psi_prior_factor=0.5, grad_psi_likeli_factor=2.0,
          correct_delta=0),                                 # test factors (HMC.cc:170-173, HMC_models.cc:461-468)
 ]
@@ -48,7 +56,7 @@ def test_forward_model_intermediates(case):
         assert rel_l2(c.e.fetch(name), ref) < TOL_FIELD
     for name, ref in zip(("posx", "posy", "posz"), (px, py, pz)):
         assert rel_l2(c.e.fetch(name), ref) < TOL_FIELD
-    rho = c.oracle.getDensity(3, px, py, pz)
+    rho = c.oracle.getDensity(c.p.mk, px, py, pz)
     assert rel_l2(c.e.fetch("rho"), rho) < TOL_FIELD
     assert rel_l2(c.e.fetch("deltaX"), dX) < TOL_FIELD
 
@@ -65,9 +73,12 @@ def test_gradient_psi_and_its_pieces(case):
         assert rel_l2(c.e.fetch("deltaX"), dX) < TOL_FIELD
         pl = c.oracle.partial_f_delta_x_log_like(dX)
         assert rel_l2(c.e.fetch("part_like"), pl) < 10 * TOL_FIELD
-        if c.p.calc_h == 2:
+        if c.p.calc_h in (2, 3):
             pos = [c.oracle.get(k) for k in ("posx", "posy", "posz")]
-            V = c.oracle.likelihood_calc_V_SPH(pl, *pos)
+            if c.p.calc_h == 2:
+                V = c.oracle.likelihood_calc_V_SPH(pl, *pos)
+            else:
+                V = c.oracle.likelihood_calc_V_SPH_fourier_TSC(pl, *pos)
             for name, ref in zip(("Vx", "Vy", "Vz"), V):
                 assert rel_l2(c.e.fetch(name), ref) < 10 * TOL_FIELD
 
@@ -158,7 +169,7 @@ def test_error_conventions():
     with pytest.raises(BchmcError) as ei:
         e = c.engine()
         e.gradient(c.q0)
-    assert ei.value.code in (2, 5)
+    assert ei.value.code == 2
     with pytest.raises(BchmcError) as ei:
         Engine(HamilParams(Nx=8, mass_type=7))
     assert ei.value.code == 4

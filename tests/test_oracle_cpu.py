@@ -9,6 +9,9 @@ from oracle.np_restatement import NpHamil
 from tests.util import Case, rel_l2
 
 CONFIGS = [
+    dict(likelihood=1, rsd_model=0, calc_h=0),
+    dict(likelihood=0, rsd_model=0, calc_h=0),
+    dict(likelihood=2, rsd_model=0, calc_h=0),
     dict(likelihood=1, rsd_model=0),
     dict(likelihood=1, rsd_model=1),
     dict(likelihood=0, rsd_model=0),
