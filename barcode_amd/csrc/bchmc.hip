@@ -71,6 +71,8 @@ struct bchmc_handle {
   int4 *hull = nullptr;
   int hull_n = 0;
   int reach = 0;
+  int hull_maxlen = 0;      // longest k-range of a hull column
+  bool hull_exact = false;  // no cell of the (2 reach + 1)^3 cube outside the hull can pass r/h <= 2
   // tile-sorted particle-mesh path
   bool tiled = false;
   TilePar tp{};
@@ -325,9 +327,12 @@ int forward_rest(bchmc_handle *h, int rsd) {
     HIPCHK(hipMemsetAsync(h->rho, 0, h->g.N * sizeof(double), h->stream));
     if (h->c.mk == 3 && h->tiled) {
       const int grid = h->tp.ntiles + (int)(h->g.N / h->tp.chunk) + 1;  // upper bound on (tile, chunk) work items
-      const size_t lds = (size_t)h->tp.lx * h->tp.ly * h->tp.lz * sizeof(double);
-      k_scatter_tile<<<grid, 256, lds, h->stream>>>(h->g, make_sph(h), h->tp, h->sx, h->sy, h->sz, h->sidx, h->t_off,
-                                                    h->t_woff, h->rho);
+      const size_t ncell = (size_t)h->tp.lx * h->tp.ly * h->tp.lz;
+      const int ncol = h->hull_exact ? h->hull_n : 0;
+      const size_t lds = ((ncell + 1) & ~(size_t)1) * sizeof(double) + ncol * sizeof(int4);
+      const int reorder = (h->tp.chunk == 2048 && !std::getenv("BCHMC_NO_SUBSORT")) ? 1 : 0;
+      k_scatter_tile<<<grid, 256, lds, h->stream>>>(h->g, make_sph(h), h->tp, h->hull, ncol, reorder, h->sx, h->sy,
+                                                    h->sz, h->sidx, h->t_off, h->t_woff, h->rho);
     } else if (h->c.mk == 3) {
       k_scatter_sph<<<nblk_full(h->g.N), 256, 0, h->stream>>>(h->g, make_pos(h, rsd), make_sph(h), h->psi, h->rho);
     } else if (h->c.mk >= 0 && h->c.mk <= 2) {
@@ -786,6 +791,25 @@ int bchmc_create(const bchmc_config *cfg, bchmc_handle **out) {
     std::vector<int4> cols;
     build_hull(cfg->particle_kernel_h, g.d, cols, h->reach);
     h->hull_n = (int)cols.size();
+    for (auto &c : cols) h->hull_maxlen = std::max(h->hull_maxlen, c.w - c.z + 1);
+    {
+      // getDensity_SPH visits the whole cube (massFunctions.cc:443-445); the hull may replace it only if every
+      // cell outside the hull is farther than 2h from ANY point of the home cell (true for h = d).
+      bool exact = true;
+      const double hh = cfg->particle_kernel_h, lim = 4. * hh * hh * (1. + 1e-9);
+      for (int i1 = -h->reach; i1 <= h->reach; ++i1)
+        for (int i2 = -h->reach; i2 <= h->reach; ++i2)
+          for (int i3 = -h->reach; i3 <= h->reach; ++i3) {
+            bool in_hull = false;
+            for (auto &c : cols)
+              if (c.x == i1 && c.y == i2 && i3 >= c.z && i3 <= c.w) in_hull = true;
+            if (in_hull) continue;
+            auto mind = [&](int i) { return std::max(std::abs(i) - 0.5 - 1e-9, 0.) * g.d; };  // home offset in [-d/2, d/2]
+            const double m2 = mind(i1) * mind(i1) + mind(i2) * mind(i2) + mind(i3) * mind(i3);
+            if (m2 <= lim) exact = false;
+          }
+      h->hull_exact = exact;
+    }
     CHK(dev_alloc(h, &h->hull, cols.size()));
     HIPCHK(hipMemcpy(h->hull, cols.data(), cols.size() * sizeof(int4), hipMemcpyHostToDevice));
     // tile-sorted particle-mesh path: tiles of 8 x 8 x 16 cells (z fastest) when they divide the grid
@@ -800,7 +824,10 @@ int bchmc_create(const bchmc_config *cfg, bchmc_handle **out) {
         tp.nty = n / tp.ty;
         tp.ntz = n / tp.tz;
         tp.ntiles = tp.ntx * tp.nty * tp.ntz;
-        tp.R = h->reach;
+        // halo: the farthest stencil offset when the hull is exact (2 for h = d), else the cube's reach
+        int hull_max = 0;
+        for (auto &c : cols) hull_max = std::max({hull_max, std::abs(c.x), std::abs(c.y), std::abs(c.z), std::abs(c.w)});
+        tp.R = h->hull_exact ? hull_max : h->reach;
         tp.lx = tp.tx + 2 * tp.R;
         tp.ly = tp.ty + 2 * tp.R;
         tp.lz = tp.tz + 2 * tp.R;

@@ -892,9 +892,24 @@ k_bin(Geo g, PosPar pp, SphPar sp, TilePar tp, const double *__restrict__ psi, i
 
 // Pass 2 (one workgroup): exclusive scans of the tile counts (-> record offsets) and of the per-tile chunk
 // counts (-> work-item offsets).  off and woff have ntiles + 1 entries.
+__device__ __forceinline__ int block_exclusive_scan_1024(int v, int *buf) {
+  const int tid = threadIdx.x;
+  buf[tid] = v;
+  __syncthreads();
+  for (int s = 1; s < 1024; s <<= 1) {
+    const int u = tid >= s ? buf[tid - s] : 0;
+    __syncthreads();
+    buf[tid] += u;
+    __syncthreads();
+  }
+  const int incl = buf[tid];
+  __syncthreads();
+  return incl - v;
+}
+
 __global__ void __launch_bounds__(1024)
 k_scan_tiles(TilePar tp, const int *__restrict__ cnt, int *__restrict__ off, int *__restrict__ woff) {
-  __shared__ int sa[1024], sb[1024];
+  __shared__ int buf[1024];
   const int T = tp.ntiles, tid = threadIdx.x;
   const int per = (T + 1023) / 1024;
   const int lo = min(tid * per, T), hi = min(lo + per, T);
@@ -903,17 +918,8 @@ k_scan_tiles(TilePar tp, const int *__restrict__ cnt, int *__restrict__ off, int
     a += cnt[t];
     b += (cnt[t] + tp.chunk - 1) / tp.chunk;
   }
-  sa[tid] = a;
-  sb[tid] = b;
-  __syncthreads();
-  for (int s = 1; s < 1024; s <<= 1) {
-    const int va = tid >= s ? sa[tid - s] : 0, vb = tid >= s ? sb[tid - s] : 0;
-    __syncthreads();
-    sa[tid] += va;
-    sb[tid] += vb;
-    __syncthreads();
-  }
-  int ea = sa[tid] - a, eb = sb[tid] - b;  // exclusive prefixes of this thread's segment
+  int ea = block_exclusive_scan_1024(a, buf);
+  int eb = block_exclusive_scan_1024(b, buf);
   for (int t = lo; t < hi; t++) {
     off[t] = ea;
     woff[t] = eb;
@@ -921,8 +927,8 @@ k_scan_tiles(TilePar tp, const int *__restrict__ cnt, int *__restrict__ off, int
     eb += (cnt[t] + tp.chunk - 1) / tp.chunk;
   }
   if (tid == 1023) {
-    off[T] = sa[1023];
-    woff[T] = sb[1023];
+    off[T] = ea;
+    woff[T] = eb;
   }
 }
 
@@ -975,14 +981,62 @@ __device__ __forceinline__ bool tile_work(const TilePar &tp, const int *__restri
 
 // getDensity_SPH on sorted particles: LDS accumulation per (tile, chunk), one flush.
 __global__ void __launch_bounds__(256)
-k_scatter_tile(Geo g, SphPar sp, TilePar tp, const double *__restrict__ sx, const double *__restrict__ sy,
-               const double *__restrict__ sz, const int *__restrict__ sidx, const int *__restrict__ off,
-               const int *__restrict__ woff, double *__restrict__ rho) {
+k_scatter_tile(Geo g, SphPar sp, TilePar tp, const int4 *__restrict__ cols, int ncol, int reorder, double *sx,
+               double *sy, double *sz, int *sidx, const int *__restrict__ off, const int *__restrict__ woff,
+               double *__restrict__ rho) {
   extern __shared__ double s_tile_acc[];
   int tile, pb, pe;
   if (!tile_work(tp, off, woff, tile, pb, pe)) return;
   const int ncell = tp.lx * tp.ly * tp.lz;
+  int4 *s_cols = reinterpret_cast<int4 *>(s_tile_acc + ((ncell + 1) & ~1));
+  for (int m = threadIdx.x; m < ncol; m += blockDim.x) s_cols[m] = cols[m];
   for (int c = threadIdx.x; c < ncell; c += blockDim.x) s_tile_acc[c] = 0.;
+  // Prologue: order this work item's records by the octant of the particle's sub-cell offset (in place, for
+  // the gather kernel too).  The 64 lanes of a wave then share the set of stencil cells that can pass the
+  // `r/h <= 2` test (51 instead of 81 on average), and a wave pays for every candidate ANY of its lanes needs.
+  // Pure reordering: results do not depend on it.
+  if (reorder) {
+    constexpr int kPer = 8;  // tp.chunk == 256 * kPer
+    __shared__ int hist[8], base[8];
+    if (threadIdx.x < 8) hist[threadIdx.x] = 0;
+    __syncthreads();
+    double rx[kPer], ry[kPer], rz[kPer];
+    int id[kPer], key[kPer], rank[kPer];
+#pragma unroll
+    for (int m = 0; m < kPer; m++) {
+      const int s = pb + (int)threadIdx.x + 256 * m;
+      if (s < pe) {
+        rx[m] = sx[s];
+        ry[m] = sy[s];
+        rz[m] = sz[s];
+        id[m] = sidx[s];
+        const double fx = rx[m] / g.d, fy = ry[m] / g.d, fz = rz[m] / g.d;
+        key[m] = (((fx - floor(fx)) >= 0.5) << 2) | (((fy - floor(fy)) >= 0.5) << 1) | ((fz - floor(fz)) >= 0.5);
+        rank[m] = atomicAdd(&hist[key[m]], 1);
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int acc = 0;
+      for (int b = 0; b < 8; b++) {
+        base[b] = acc;
+        acc += hist[b];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < kPer; m++) {
+      const int s = pb + (int)threadIdx.x + 256 * m;
+      if (s < pe) {
+        const int dst = pb + base[key[m]] + rank[m];
+        sx[dst] = rx[m];
+        sy[dst] = ry[m];
+        sz[dst] = rz[m];
+        sidx[dst] = id[m];
+      }
+    }
+    __threadfence_block();
+  }
   __syncthreads();
   const int tzi = tile % tp.ntz, tyi = (tile / tp.ntz) % tp.nty, txi = tile / (tp.ntz * tp.nty);
   const int ox = txi * tp.tx - tp.R, oy = tyi * tp.ty - tp.R, oz = tzi * tp.tz - tp.R;  // global cell of LDS (0,0,0)
@@ -997,21 +1051,41 @@ k_scatter_tile(Geo g, SphPar sp, TilePar tp, const double *__restrict__ sx, cons
     if ((unsigned)(hx - tp.R) >= (unsigned)tp.tx || (unsigned)(hy - tp.R) >= (unsigned)tp.ty ||
         (unsigned)(hz - tp.R) >= (unsigned)tp.tz)
       continue;  // cannot happen (binning and this kernel see the same stored position); keeps LDS indexing safe
-    for (int i1 = -R; i1 <= R; ++i1) {
-      const double dx = x - (ccx + (double)i1 * d);
-      const double dx2 = dx * dx;
-      if (dx2 > sp.r2_lim) continue;
-      for (int i2 = -R; i2 <= R; ++i2) {
-        const double dy = y - (ccy + (double)i2 * d);
-        const double r2ab = dx2 + dy * dy;
+    if (ncol > 0) {
+      // Exact hull (host-verified: no cell outside it can satisfy r/h <= 2): 81 candidates instead of 343.
+      for (int m = 0; m < ncol; ++m) {
+        const int4 c = s_cols[m];
+        const double dx = x - (ccx + (double)c.x * d);
+        const double dy = y - (ccy + (double)c.y * d);
+        const double r2ab = dx * dx + dy * dy;
         if (r2ab > sp.r2_lim) continue;
-        double *row = s_tile_acc + tp.lz * ((hy + i2) + tp.ly * (hx + i1)) + hz;
-        for (int i3 = -R; i3 <= R; ++i3) {
+        double *row = s_tile_acc + tp.lz * ((hy + c.y) + tp.ly * (hx + c.x)) + hz;
+        for (int i3 = c.z; i3 <= c.w; ++i3) {
           const double dz = z - (ccz + (double)i3 * d);
           const double r2 = r2ab + dz * dz;
-          if (r2 > sp.r2_lim) continue;
-          const double q = (r2 * fast_rsqrt(fmax(r2, 1e-280))) * sp.h_inv;
-          if (q <= 2.) atomic_add_f64(row + i3, sph_w_sel(q, sp.w_norm));
+          if (r2 <= sp.r2_lim) {
+            const double q = (r2 * fast_rsqrt(fmax(r2, 1e-280))) * sp.h_inv;
+            if (q <= 2.) atomic_add_f64(row + i3, sph_w_sel(q, sp.w_norm));
+          }
+        }
+      }
+    } else {
+      for (int i1 = -R; i1 <= R; ++i1) {
+        const double dx = x - (ccx + (double)i1 * d);
+        const double dx2 = dx * dx;
+        if (dx2 > sp.r2_lim) continue;
+        for (int i2 = -R; i2 <= R; ++i2) {
+          const double dy = y - (ccy + (double)i2 * d);
+          const double r2ab = dx2 + dy * dy;
+          if (r2ab > sp.r2_lim) continue;
+          double *row = s_tile_acc + tp.lz * ((hy + i2) + tp.ly * (hx + i1)) + hz;
+          for (int i3 = -R; i3 <= R; ++i3) {
+            const double dz = z - (ccz + (double)i3 * d);
+            const double r2 = r2ab + dz * dz;
+            if (r2 > sp.r2_lim) continue;
+            const double q = (r2 * fast_rsqrt(fmax(r2, 1e-280))) * sp.h_inv;
+            if (q <= 2.) atomic_add_f64(row + i3, sph_w_sel(q, sp.w_norm));
+          }
         }
       }
     }
@@ -1068,11 +1142,12 @@ k_gather_tile(Geo g, HullPar hp, TilePar tp, int rsd, const double *__restrict__
       double zh = dpcz - (double)c.z * d_h;
       for (int i3 = c.z; i3 <= c.w; ++i3) {
         const double q_sq = r2ab + zh * zh;
-        const double partial = (q_sq <= 4.) ? sph_grad_partial(q_sq, hp.norm) : 0.;
-        const double common = row[i3] * partial;
-        vx += common * xh;
-        vy += common * yh;
-        vz += common * zh;
+        if (q_sq <= 4.) {
+          const double common = row[i3] * sph_grad_partial(q_sq, hp.norm);
+          vx += common * xh;
+          vy += common * yh;
+          vz += common * zh;
+        }
         zh -= d_h;
       }
     }

@@ -22,7 +22,7 @@ CONFIGS = [
     dict(likelihood=1, rsd_model=0, mass_type=5),          # Fourier + real-space mass
     dict(likelihood=1, rsd_model=0, calc_h=1),             # h = partial_f (HMC_models.cc:413-415)
     dict(likelihood=1, rsd_model=0, calc_h=0),             # legacy likelihood_calc_h, spectral gradient
-    dict(likelihood=0, rsd_model=0, calc_h=0, mk=1),       # legacy, finite differences, CIC
+    dict(likelihood=0, rsd_model=0, calc_h=0, mk=1, eps_scale=0.01),  # legacy, finite differences, CIC
     dict(likelihood=2, rsd_model=0, calc_h=0, eps_scale=1e-3),  # legacy, finite differences of log density (stiff)
     dict(likelihood=1, rsd_model=0, calc_h=3),             # Fourier + TSC variant of V (HMC_models_testing.cpp:54-188)
     dict(likelihood=1, rsd_model=1, calc_h=3, sfmodel=2),
