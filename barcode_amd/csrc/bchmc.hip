@@ -4,6 +4,9 @@
 // Trajectory layout: q and p live in Fourier space for the whole trajectory, so one
 // leapfrog step costs 3 C2R (displacements) + 3 R2C (V components) instead of the reference's 12 FFTs
 // (SURVEY.md 2.1 "FFT count per leapfrog step").
+//
+// The pipeline is a template on the storage type T of the field arrays (double: reference DOUBLE_PREC;
+// float: BASELINE config 5, "fp32 field arrays"); the C ABI always exchanges double arrays.
 #include "../../include/bchmc.h"
 #include "kernels.hpp"
 
@@ -17,6 +20,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 using namespace bchmc;
@@ -36,6 +40,8 @@ struct ProfRec {
 struct bchmc_handle {
   bchmc_config c{};
   Geo g{};
+  bool f32 = false;   // storage type of the field arrays
+  size_t esz = 8;     // sizeof(T)
   int mass_fs = 0, mass_rs = 0;
   hipStream_t stream = nullptr;
   std::string err;
@@ -46,28 +52,29 @@ struct bchmc_handle {
   void *work = nullptr;
   size_t work_bytes = 0;
 
-  // inputs (N doubles each) + derived half-layout multipliers
-  double *in_arr[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  // inputs (N elements of T each) + derived half-layout multipliers (always double)
+  void *in_arr[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   bool have[6] = {false, false, false, false, false, false};
   double *wS = nullptr, *wM = nullptr;  // normFS / signal_PS, normFS / mass_f on the half-complex layout
 
-  // state and scratch
-  double2 *qk = nullptr, *pk = nullptr, *gk = nullptr;  // Nh each
-  double2 *Ck = nullptr;                                // 3 Nh: Psi^ / V^
-  double2 *tC = nullptr;                                // Nh scratch
-  double *psi = nullptr;                                // 3 N: displacement components
-  double *V = nullptr;                                  // 3 N: V components
-  double *rho = nullptr, *plike = nullptr;              // N each
-  double *ioq = nullptr, *iop = nullptr;                // N each: staging / scratch
-  double *gprior = nullptr, *glike = nullptr;           // N each, lazily allocated by bchmc_gradient
-  double *conv = nullptr;                               // 3 N, lazily allocated for calc_h = 3
-  double *convF = nullptr;                              // Nh: SPH kernel transform table for calc_h = 3
-  double *rho_part = nullptr, *partA = nullptr;         // kRedBlocks doubles each
-  double *guard = nullptr;                              // guard slots, one per step
+  // state and scratch (T / C2<T>)
+  void *qk = nullptr, *pk = nullptr, *gk = nullptr;  // Nh complex each
+  void *Ck = nullptr;                                // 3 Nh: Psi^ / V^
+  void *tC = nullptr;                                // Nh scratch
+  void *psi = nullptr;                               // 3 N: displacement components
+  void *V = nullptr;                                 // 3 N: V components
+  void *rho = nullptr, *plike = nullptr;             // N each
+  void *ioq = nullptr, *iop = nullptr;               // N each: staging / scratch
+  void *gprior = nullptr, *glike = nullptr;          // N each, lazily allocated by bchmc_gradient
+  void *conv = nullptr;                              // 3 N, lazily allocated for calc_h 0 / 3
+  double *convF = nullptr;                           // Nh: SPH kernel transform table for calc_h = 3
+  double *dstage = nullptr;                          // 2 N doubles: ABI <-> T conversion staging
+  double *rho_part = nullptr, *partA = nullptr;      // kRedBlocks doubles each
+  double *guard = nullptr;                           // guard slots, one per step
   size_t guard_cap = 0;
   int *stop = nullptr;
   unsigned long long *steps_done = nullptr;
-  double *h_part = nullptr;                             // pinned host staging for partials
+  double *h_part = nullptr;                          // pinned host staging for partials
   int4 *hull = nullptr;
   int hull_n = 0;
   int reach = 0;
@@ -78,7 +85,7 @@ struct bchmc_handle {
   TilePar tp{};
   int *t_cnt = nullptr, *t_off = nullptr, *t_woff = nullptr;  // ntiles, ntiles+1, ntiles+1
   int2 *t_rank = nullptr;                                      // N
-  double *sx = nullptr, *sy = nullptr, *sz = nullptr;          // N each: sorted positions
+  void *sx = nullptr, *sy = nullptr, *sz = nullptr;            // N each: sorted positions
   int *sidx = nullptr;                                         // N: original index | flags
   bool sorted_valid = false;
   bool have_eval = false;  // rho / psi hold a forward evaluation
@@ -120,11 +127,14 @@ struct bchmc_handle {
 
 namespace {
 
-template <typename T>
-int dev_alloc(bchmc_handle *h, T **p, size_t count) {
-  hipError_t e = hipMalloc((void **)p, count * sizeof(T));
-  if (e != hipSuccess) return h->fail(BCHMC_ERR_NOMEM, "hipMalloc(%zu bytes): %s", count * sizeof(T), hipGetErrorString(e));
+int dev_alloc_bytes(bchmc_handle *h, void **p, size_t bytes) {
+  hipError_t e = hipMalloc(p, bytes);
+  if (e != hipSuccess) return h->fail(BCHMC_ERR_NOMEM, "hipMalloc(%zu bytes): %s", bytes, hipGetErrorString(e));
   return BCHMC_OK;
+}
+template <typename U>
+int dev_alloc(bchmc_handle *h, U **p, size_t count) {
+  return dev_alloc_bytes(h, (void **)p, count * sizeof(U));
 }
 
 inline int nblk_stride(long long n) { return (int)std::min<long long>((n + 255) / 256, 2048); }
@@ -168,7 +178,7 @@ void prof_collect(bchmc_handle *h) {
   h->prof_recs.clear();
 }
 
-// ---- FFT wrappers (unnormalised both ways; callers fold 1/N into the preceding k-space kernel) ------
+// ---- FFT wrapper (unnormalised both ways; callers fold 1/N into the preceding k-space kernel) -------
 int fft_exec(bchmc_handle *h, rocfft_plan plan, void *in, void *out, int cls) {
   ProfScope ps(h, cls);
   void *ib[1] = {in}, *ob[1] = {out};
@@ -208,7 +218,7 @@ SphPar make_sph(const bchmc_handle *h) {
   sp.h = h->c.particle_kernel_h;
   sp.h_inv = 1. / sp.h;
   sp.w_norm = 1. / M_PI / (sp.h * sp.h * sp.h);
-  sp.r2_lim = 4. * sp.h * sp.h * (1. + 1e-12);
+  sp.r2_lim = 4. * sp.h * sp.h * (1. + (h->f32 ? 1e-5 : 1e-12));
   sp.min1 = h->c.min1;
   sp.min2 = h->c.min2;
   sp.min3 = h->c.min3;
@@ -271,14 +281,13 @@ int need_input(bchmc_handle *h, int f, const char *name) {
   return BCHMC_OK;
 }
 
-int check_inputs(bchmc_handle *h, bool force) {
+int check_inputs(bchmc_handle *h) {
   CHK(need_input(h, BCHMC_F_SIGNAL_PS, "signal_PS"));
   if (h->mass_fs) CHK(need_input(h, BCHMC_F_MASS_F, "mass_f"));
   if (h->mass_rs) CHK(need_input(h, BCHMC_F_MASS_R, "mass_r"));
   CHK(need_input(h, BCHMC_F_NOBS, "nobs"));
   CHK(need_input(h, BCHMC_F_WINDOW, "window"));
   if (h->c.likelihood != 0) CHK(need_input(h, BCHMC_F_NOISE, "noise"));
-  (void)force;
   return BCHMC_OK;
 }
 
@@ -289,67 +298,6 @@ int host_sum(bchmc_handle *h, const double *d_part, double *out) {
   double s = 0.;
   for (int i = 0; i < kRedBlocks; i++) s += h->h_part[i];
   *out = s;
-  return BCHMC_OK;
-}
-
-// ---- building blocks of one force / energy evaluation ---------------------------------------------------
-
-// Psi^ from the current q^ (no kick, no drift)
-int launch_za(bchmc_handle *h, double dq_factor) {
-  ProfScope ps(h, BCHMC_K_KSPACE_DRIFT_ZA);
-  StepCtl ctl{h->stop, h->steps_done, nullptr, 0., 0};
-  const double c_za = -h->c.D1 * dq_factor / (double)h->g.N;
-  k_kick_drift_za<false><<<nblk_stride(h->g.Nh), 256, 0, h->stream>>>(h->g, h->qk, h->pk, h->gk, nullptr, nullptr,
-                                                                       h->Ck, 0., 0., c_za, ctl);
-  HIPCHK(hipGetLastError());
-  return BCHMC_OK;
-}
-
-// C2R of the three displacement components, mass assignment, sum of rho.  Lag2Eul.cc:90-131 / 363-423.
-int forward_rest(bchmc_handle *h, int rsd) {
-  if (rsd && !h->c.planepar) return h->fail(BCHMC_ERR_RSD_NOT_PLANEPAR, "non-plane-parallel RSD is not implemented");
-  CHK(fft_exec(h, h->c2r3, h->Ck, h->psi, BCHMC_K_FFT_C2R));
-  h->sorted_valid = false;
-  if (h->c.mk == 3 && h->tiled) {
-    // counting sort of the particles by the Eulerian tile of their home cell
-    ProfScope ps(h, BCHMC_K_SORT);
-    HIPCHK(hipMemsetAsync(h->t_cnt, 0, h->tp.ntiles * sizeof(int), h->stream));
-    const PosPar pp = make_pos(h, rsd);
-    k_bin<<<nblk_full(h->g.N), 256, 0, h->stream>>>(h->g, pp, make_sph(h), h->tp, h->psi, h->t_cnt, h->t_rank, h->V);
-    k_scan_tiles<<<1, 1024, 0, h->stream>>>(h->tp, h->t_cnt, h->t_off, h->t_woff);
-    k_reorder<<<nblk_full(h->g.N), 256, 0, h->stream>>>(h->g, pp, h->psi, h->t_rank, h->t_off, h->sx, h->sy, h->sz,
-                                                        h->sidx);
-    HIPCHK(hipGetLastError());
-    h->sorted_valid = true;
-  }
-  {
-    ProfScope ps(h, BCHMC_K_SCATTER);
-    HIPCHK(hipMemsetAsync(h->rho, 0, h->g.N * sizeof(double), h->stream));
-    if (h->c.mk == 3 && h->tiled) {
-      const int grid = h->tp.ntiles + (int)(h->g.N / h->tp.chunk) + 1;  // upper bound on (tile, chunk) work items
-      const size_t ncell = (size_t)h->tp.lx * h->tp.ly * h->tp.lz;
-      const int ncol = h->hull_exact ? h->hull_n : 0;
-      const size_t lds = ((ncell + 1) & ~(size_t)1) * sizeof(double) + ncol * sizeof(int4);
-      const int reorder = (h->tp.chunk == 2048 && !std::getenv("BCHMC_NO_SUBSORT")) ? 1 : 0;
-      k_scatter_tile<<<grid, 256, lds, h->stream>>>(h->g, make_sph(h), h->tp, h->hull, ncol, reorder, h->sx, h->sy,
-                                                    h->sz, h->sidx, h->t_off, h->t_woff, h->rho);
-    } else if (h->c.mk == 3) {
-      k_scatter_sph<<<nblk_full(h->g.N), 256, 0, h->stream>>>(h->g, make_pos(h, rsd), make_sph(h), h->psi, h->rho);
-    } else if (h->c.mk >= 0 && h->c.mk <= 2) {
-      k_scatter_low_order<<<nblk_full(h->g.N), 256, 0, h->stream>>>(h->g, make_pos(h, rsd), make_sph(h), h->c.mk, h->psi,
-                                                                    h->rho);
-    } else {
-      return h->fail(BCHMC_ERR_ARG, "masskernel %d is not a valid value (0..3)", h->c.mk);
-    }
-    HIPCHK(hipGetLastError());
-  }
-  {
-    ProfScope ps(h, BCHMC_K_MEAN_PARTIAL);
-    k_sum<<<kRedBlocks, 256, 0, h->stream>>>(h->rho, h->g.N, h->rho_part);
-    HIPCHK(hipGetLastError());
-  }
-  h->have_eval = true;
-  h->last_rsd = rsd;
   return BCHMC_OK;
 }
 
@@ -384,272 +332,464 @@ int build_conv_table(bchmc_handle *h) {
   return BCHMC_OK;
 }
 
-// After forward_rest: leaves the k-space likelihood source in Ck and returns the assemble mode.
-int like_force(bchmc_handle *h, int *like_mode) {
-  if (h->c.calc_h == 2 || h->c.calc_h == 3) {
-    if (h->c.mk != 3)
-      return h->fail(BCHMC_ERR_MK_NOT_SPH, "Must use SPH mass kernel (masskernel = 3) with calc_h = 2 or 3");
-  } else if (h->c.calc_h != 1 && h->c.calc_h != 0) {
-    return h->fail(BCHMC_ERR_ARG, "calc_h = %d is not a valid value (0..3)", h->c.calc_h);
+// ======================================================================================================
+// The pipeline, for storage type T
+// ======================================================================================================
+template <typename T>
+struct Pipe {
+  using CT = C2<T>;
+  static constexpr bool kDouble = std::is_same<T, double>::value;
+
+  static T *R(void *p) { return reinterpret_cast<T *>(p); }
+  static CT *C(void *p) { return reinterpret_cast<CT *>(p); }
+
+  static size_t tile_lds(const bchmc_handle *h, int ncol, size_t cell_bytes) {
+    const size_t ncell = (size_t)h->tp.lx * h->tp.ly * h->tp.lz;
+    return ((ncell * cell_bytes + 15) & ~(size_t)15) + (size_t)ncol * sizeof(int4);
   }
-  {
-    ProfScope ps(h, BCHMC_K_MEAN_PARTIAL);
-    k_partial_like<<<nblk_stride(h->g.N), 256, 0, h->stream>>>(h->g, make_like(h), h->rho, h->rho_part,
-                                                               h->in_arr[BCHMC_F_NOBS], h->in_arr[BCHMC_F_NOISE],
-                                                               h->in_arr[BCHMC_F_WINDOW], h->plike);
-    HIPCHK(hipGetLastError());
-  }
-  if (h->c.calc_h == 1) {
-    CHK(fft_exec(h, h->r2c1, h->plike, h->Ck, BCHMC_K_FFT_R2C));
-    *like_mode = 1;
-    return BCHMC_OK;
-  }
-  if (h->c.calc_h == 0) {
-    // likelihood_calc_h (HMC_models_testing.cpp:25-50)
-    {
-      ProfScope ps(h, BCHMC_K_OTHER);
-      k_overdens<<<nblk_stride(h->g.N), 256, 0, h->stream>>>(h->g, h->rho, h->rho_part, h->ioq);
+
+  // ---- ABI (double) <-> storage (T) on the device ----
+  static int load_real(bchmc_handle *h, const double *d_src, T *dst) {
+    if (kDouble) {
+      if ((const void *)d_src != (const void *)dst)
+        HIPCHK(hipMemcpyAsync(dst, d_src, h->g.N * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    } else {
+      k_convert<double, T><<<nblk_stride(h->g.N), 256, 0, h->stream>>>(h->g.N, d_src, dst);
       HIPCHK(hipGetLastError());
     }
-    if (h->c.likelihood == 1) {
-      if (!h->conv) CHK(dev_alloc(h, &h->conv, 3 * (size_t)h->g.N));
-      CHK(fft_exec(h, h->r2c1, h->ioq, h->tC, BCHMC_K_FFT_R2C));
+    return BCHMC_OK;
+  }
+  static int store_real(bchmc_handle *h, const T *src, double *d_dst) {
+    if (kDouble) {
+      if ((const void *)src != (const void *)d_dst)
+        HIPCHK(hipMemcpyAsync(d_dst, src, h->g.N * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    } else {
+      k_convert<T, double><<<nblk_stride(h->g.N), 256, 0, h->stream>>>(h->g.N, src, d_dst);
+      HIPCHK(hipGetLastError());
+    }
+    return BCHMC_OK;
+  }
+
+  // ---- building blocks of one force / energy evaluation ----
+
+  // Psi^ from the current q^ (no kick, no drift)
+  static int launch_za(bchmc_handle *h, double dq_factor) {
+    ProfScope ps(h, BCHMC_K_KSPACE_DRIFT_ZA);
+    StepCtl ctl{h->stop, h->steps_done, nullptr, 0., 0};
+    const double c_za = -h->c.D1 * dq_factor / (double)h->g.N;
+    k_kick_drift_za<T, false><<<nblk_stride(h->g.Nh), 256, 0, h->stream>>>(h->g, C(h->qk), C(h->pk), C(h->gk), nullptr,
+                                                                          nullptr, C(h->Ck), 0., 0., c_za, ctl);
+    HIPCHK(hipGetLastError());
+    return BCHMC_OK;
+  }
+
+  // C2R of the three displacement components, mass assignment, sum of rho.  Lag2Eul.cc:90-131 / 363-423.
+  static int forward_rest(bchmc_handle *h, int rsd) {
+    if (rsd && !h->c.planepar) return h->fail(BCHMC_ERR_RSD_NOT_PLANEPAR, "non-plane-parallel RSD is not implemented");
+    CHK(fft_exec(h, h->c2r3, h->Ck, h->psi, BCHMC_K_FFT_C2R));
+    h->sorted_valid = false;
+    const PosPar pp = make_pos(h, rsd);
+    const SphPar sp = make_sph(h);
+    if (h->c.mk == 3 && h->tiled) {
+      // counting sort of the particles by the Eulerian tile of their home cell
+      ProfScope ps(h, BCHMC_K_SORT);
+      HIPCHK(hipMemsetAsync(h->t_cnt, 0, h->tp.ntiles * sizeof(int), h->stream));
+      k_bin<T><<<nblk_full(h->g.N), 256, 0, h->stream>>>(h->g, pp, sp, h->tp, R(h->psi), h->t_cnt, h->t_rank, R(h->V));
+      k_scan_tiles<<<1, 1024, 0, h->stream>>>(h->tp, h->t_cnt, h->t_off, h->t_woff);
+      k_reorder<T><<<nblk_full(h->g.N), 256, 0, h->stream>>>(h->g, pp, R(h->psi), h->t_rank, h->t_off, R(h->sx),
+                                                             R(h->sy), R(h->sz), h->sidx);
+      HIPCHK(hipGetLastError());
+      h->sorted_valid = true;
+    }
+    {
+      ProfScope ps(h, BCHMC_K_SCATTER);
+      HIPCHK(hipMemsetAsync(h->rho, 0, h->g.N * sizeof(T), h->stream));
+      if (h->c.mk == 3 && h->tiled) {
+        const int grid = h->tp.ntiles + (int)(h->g.N / h->tp.chunk) + 1;  // upper bound on (tile, chunk) work items
+        const int ncol = h->hull_exact ? h->hull_n : 0;
+        const int reorder = (h->tp.chunk == 2048 && !std::getenv("BCHMC_NO_SUBSORT")) ? 1 : 0;
+        k_scatter_tile<T><<<grid, 256, tile_lds(h, ncol, sizeof(double)), h->stream>>>(h->g, sp, h->tp, h->hull, ncol, reorder, R(h->sx),
+                                                                       R(h->sy), R(h->sz), h->sidx, h->t_off, h->t_woff,
+                                                                       R(h->rho));
+      } else if (h->c.mk == 3) {
+        k_scatter_sph<T><<<nblk_full(h->g.N), 256, 0, h->stream>>>(h->g, pp, sp, R(h->psi), R(h->rho));
+      } else if (h->c.mk >= 0 && h->c.mk <= 2) {
+        k_scatter_low_order<T><<<nblk_full(h->g.N), 256, 0, h->stream>>>(h->g, pp, sp, h->c.mk, R(h->psi), R(h->rho));
+      } else {
+        return h->fail(BCHMC_ERR_ARG, "masskernel %d is not a valid value (0..3)", h->c.mk);
+      }
+      HIPCHK(hipGetLastError());
+    }
+    {
+      ProfScope ps(h, BCHMC_K_MEAN_PARTIAL);
+      k_sum<T><<<kRedBlocks, 256, 0, h->stream>>>(R(h->rho), h->g.N, h->rho_part);
+      HIPCHK(hipGetLastError());
+    }
+    h->have_eval = true;
+    h->last_rsd = rsd;
+    return BCHMC_OK;
+  }
+
+  static int ensure_conv(bchmc_handle *h) {
+    if (!h->conv) CHK(dev_alloc_bytes(h, &h->conv, 3 * (size_t)h->g.N * sizeof(T)));
+    return BCHMC_OK;
+  }
+
+  // After forward_rest: leaves the k-space likelihood source in Ck and returns the assemble mode.
+  static int like_force(bchmc_handle *h, int *like_mode) {
+    if (h->c.calc_h == 2 || h->c.calc_h == 3) {
+      if (h->c.mk != 3)
+        return h->fail(BCHMC_ERR_MK_NOT_SPH, "Must use SPH mass kernel (masskernel = 3) with calc_h = 2 or 3");
+    } else if (h->c.calc_h != 1 && h->c.calc_h != 0) {
+      return h->fail(BCHMC_ERR_ARG, "calc_h = %d is not a valid value (0..3)", h->c.calc_h);
+    }
+    const long long N = h->g.N, Nh = h->g.Nh;
+    {
+      ProfScope ps(h, BCHMC_K_MEAN_PARTIAL);
+      k_partial_like<T><<<nblk_stride(N), 256, 0, h->stream>>>(h->g, make_like(h), R(h->rho), h->rho_part,
+                                                               R(h->in_arr[BCHMC_F_NOBS]), R(h->in_arr[BCHMC_F_NOISE]),
+                                                               R(h->in_arr[BCHMC_F_WINDOW]), R(h->plike));
+      HIPCHK(hipGetLastError());
+    }
+    if (h->c.calc_h == 1) {
+      CHK(fft_exec(h, h->r2c1, h->plike, h->Ck, BCHMC_K_FFT_R2C));
+      *like_mode = 1;
+      return BCHMC_OK;
+    }
+    if (h->c.calc_h == 0) {
+      // likelihood_calc_h (HMC_models_testing.cpp:25-50)
       {
         ProfScope ps(h, BCHMC_K_OTHER);
-        k_gradfft_mult<<<nblk_stride(h->g.Nh), 256, 0, h->stream>>>(h->g, h->tC, h->Ck, 1. / (double)h->g.N);
+        k_overdens<T><<<nblk_stride(N), 256, 0, h->stream>>>(h->g, R(h->rho), h->rho_part, R(h->ioq));
+        HIPCHK(hipGetLastError());
+      }
+      if (h->c.likelihood == 1) {
+        CHK(ensure_conv(h));
+        CHK(fft_exec(h, h->r2c1, h->ioq, h->tC, BCHMC_K_FFT_R2C));
+        {
+          ProfScope ps(h, BCHMC_K_OTHER);
+          k_gradfft_mult<T><<<nblk_stride(Nh), 256, 0, h->stream>>>(h->g, C(h->tC), C(h->Ck), 1. / (double)N);
+          HIPCHK(hipGetLastError());
+        }
+        CHK(fft_exec(h, h->c2r3, h->Ck, h->conv, BCHMC_K_FFT_C2R));
+        ProfScope ps(h, BCHMC_K_OTHER);
+        k_mul3<T><<<nblk_stride(N), 256, 0, h->stream>>>(N, R(h->plike), R(h->conv), R(h->V));
+        HIPCHK(hipGetLastError());
+      } else {
+        ProfScope ps(h, BCHMC_K_OTHER);
+        k_findif_mul<T><<<nblk_stride(N), 256, 0, h->stream>>>(h->g, make_like(h), R(h->ioq), R(h->plike), R(h->V));
+        HIPCHK(hipGetLastError());
+      }
+      CHK(fft_exec(h, h->r2c3, h->V, h->Ck, BCHMC_K_FFT_R2C));
+      *like_mode = 0;
+      return BCHMC_OK;
+    }
+    if (h->c.calc_h == 3) {
+      // likelihood_calc_V_SPH_fourier_TSC (HMC_models_testing.cpp:54-188)
+      if (h->last_rsd && !h->c.planepar)
+        return h->fail(BCHMC_ERR_RSD_NOT_PLANEPAR, "non-plane-parallel RSD is not implemented in calc_V");
+      CHK(ensure_conv(h));
+      if (!h->convF) CHK(build_conv_table(h));
+      CHK(fft_exec(h, h->r2c1, h->plike, h->tC, BCHMC_K_FFT_R2C));
+      const double hh = h->c.particle_kernel_h;
+      {
+        ProfScope ps(h, BCHMC_K_OTHER);
+        k_conv_kernel<T><<<nblk_stride(Nh), 256, 0, h->stream>>>(h->g, C(h->tC), h->convF, C(h->Ck), hh, 1. / (double)N);
         HIPCHK(hipGetLastError());
       }
       CHK(fft_exec(h, h->c2r3, h->Ck, h->conv, BCHMC_K_FFT_C2R));
-      ProfScope ps(h, BCHMC_K_OTHER);
-      k_mul3<<<nblk_stride(h->g.N), 256, 0, h->stream>>>(h->g.N, h->plike, h->conv, h->V);
-      HIPCHK(hipGetLastError());
+      {
+        ProfScope ps(h, BCHMC_K_GATHER);
+        k_interp_tsc<T><<<nblk_full(N), 256, 0, h->stream>>>(h->g, make_pos(h, h->last_rsd),
+                                                             fgrow1(h->c.ascale, h->c.OM, h->c.OL), R(h->psi),
+                                                             R(h->conv), R(h->V));
+        HIPCHK(hipGetLastError());
+      }
     } else {
-      ProfScope ps(h, BCHMC_K_OTHER);
-      k_findif_mul<<<nblk_stride(h->g.N), 256, 0, h->stream>>>(h->g, make_like(h), h->ioq, h->plike, h->V);
+      ProfScope ps(h, BCHMC_K_GATHER);
+      HullPar hp = make_hull(h);
+      if (h->tiled && h->sorted_valid) {
+        const int grid = h->tp.ntiles + (int)(N / h->tp.chunk) + 1;
+        k_gather_tile<T><<<grid, 256, tile_lds(h, hp.ncol, sizeof(T)), h->stream>>>(h->g, hp, h->tp, h->last_rsd, R(h->sx),
+                                                                         R(h->sy), R(h->sz), h->sidx, h->t_off,
+                                                                         h->t_woff, R(h->plike), R(h->V));
+      } else {
+        k_gather_sph<T><<<nblk_full(N), 256, hp.ncol * sizeof(int4), h->stream>>>(h->g, make_pos(h, h->last_rsd), hp,
+                                                                                  R(h->psi), R(h->plike), R(h->V));
+      }
       HIPCHK(hipGetLastError());
     }
     CHK(fft_exec(h, h->r2c3, h->V, h->Ck, BCHMC_K_FFT_R2C));
     *like_mode = 0;
     return BCHMC_OK;
   }
-  if (h->c.calc_h == 3) {
-    // likelihood_calc_V_SPH_fourier_TSC (HMC_models_testing.cpp:54-188)
-    if (h->last_rsd && !h->c.planepar)
-      return h->fail(BCHMC_ERR_RSD_NOT_PLANEPAR, "non-plane-parallel RSD is not implemented in calc_V");
-    if (!h->conv) CHK(dev_alloc(h, &h->conv, 3 * (size_t)h->g.N));
-    if (!h->convF) CHK(build_conv_table(h));
-    CHK(fft_exec(h, h->r2c1, h->plike, h->tC, BCHMC_K_FFT_R2C));
-    const double hh = h->c.particle_kernel_h;
+
+  // GRF likelihood force (gaussian_random_field.cpp:25-37): needs q in real space.
+  static int grf_force(bchmc_handle *h) {
     {
       ProfScope ps(h, BCHMC_K_OTHER);
-      k_conv_kernel<<<nblk_stride(h->g.Nh), 256, 0, h->stream>>>(h->g, h->tC, h->convF, h->Ck, hh, 1. / (double)h->g.N);
+      k_scale_c<T><<<nblk_stride(h->g.Nh), 256, 0, h->stream>>>(h->g.Nh, C(h->qk), C(h->tC), 1. / (double)h->g.N);
       HIPCHK(hipGetLastError());
     }
-    CHK(fft_exec(h, h->c2r3, h->Ck, h->conv, BCHMC_K_FFT_C2R));
+    CHK(fft_exec(h, h->c2r1, h->tC, h->plike, BCHMC_K_FFT_C2R));
     {
-      ProfScope ps(h, BCHMC_K_GATHER);
-      k_interp_tsc<<<nblk_full(h->g.N), 256, 0, h->stream>>>(h->g, make_pos(h, h->last_rsd),
-                                                             fgrow1(h->c.ascale, h->c.OM, h->c.OL), h->psi, h->conv, h->V);
+      ProfScope ps(h, BCHMC_K_OTHER);
+      k_grf_grad<T><<<nblk_stride(h->g.N), 256, 0, h->stream>>>(h->g.N, R(h->plike), R(h->in_arr[BCHMC_F_NOBS]),
+                                                                R(h->in_arr[BCHMC_F_NOISE]),
+                                                                R(h->in_arr[BCHMC_F_WINDOW]), R(h->rho));
       HIPCHK(hipGetLastError());
     }
-  } else {
-    ProfScope ps(h, BCHMC_K_GATHER);
-    HullPar hp = make_hull(h);
-    if (h->tiled && h->sorted_valid) {
-      const int grid = h->tp.ntiles + (int)(h->g.N / h->tp.chunk) + 1;
-      const size_t ncell = (size_t)h->tp.lx * h->tp.ly * h->tp.lz;
-      const size_t lds = ((ncell + 1) & ~(size_t)1) * sizeof(double) + hp.ncol * sizeof(int4);
-      k_gather_tile<<<grid, 256, lds, h->stream>>>(h->g, hp, h->tp, h->last_rsd, h->sx, h->sy, h->sz, h->sidx,
-                                                   h->t_off, h->t_woff, h->plike, h->V);
-    } else {
-      k_gather_sph<<<nblk_full(h->g.N), 256, hp.ncol * sizeof(int4), h->stream>>>(h->g, make_pos(h, h->last_rsd), hp,
-                                                                                  h->psi, h->plike, h->V);
-    }
-    HIPCHK(hipGetLastError());
-  }
-  CHK(fft_exec(h, h->r2c3, h->V, h->Ck, BCHMC_K_FFT_R2C));
-  *like_mode = 0;
-  return BCHMC_OK;
-}
-
-// GRF likelihood force (gaussian_random_field.cpp:25-37): needs q in real space.
-int grf_force(bchmc_handle *h) {
-  {
-    ProfScope ps(h, BCHMC_K_OTHER);
-    k_scale_c<<<nblk_stride(h->g.Nh), 256, 0, h->stream>>>(h->g.Nh, h->qk, h->tC, 1. / (double)h->g.N);
-    HIPCHK(hipGetLastError());
-  }
-  CHK(fft_exec(h, h->c2r1, h->tC, h->plike, BCHMC_K_FFT_C2R));
-  {
-    ProfScope ps(h, BCHMC_K_OTHER);
-    k_grf_grad<<<nblk_stride(h->g.N), 256, 0, h->stream>>>(h->g.N, h->plike, h->in_arr[BCHMC_F_NOBS],
-                                                           h->in_arr[BCHMC_F_NOISE], h->in_arr[BCHMC_F_WINDOW], h->rho);
-    HIPCHK(hipGetLastError());
-  }
-  CHK(fft_exec(h, h->r2c1, h->rho, h->Ck, BCHMC_K_FFT_R2C));
-  h->have_eval = false;
-  return BCHMC_OK;
-}
-
-// Likelihood part of gradient_psi from the current q^: fills Ck, returns (like_mode, b).
-// pre_za: Psi^ is already in Ck (the fused kick+drift+ZA kernel ran).
-int force_sources(bchmc_handle *h, bool pre_za, int *like_mode, double *b) {
-  if (h->c.likelihood == 3) {
-    CHK(grf_force(h));
-    *like_mode = 1;
-    *b = h->c.grad_psi_likeli_factor;
+    CHK(fft_exec(h, h->r2c1, h->rho, h->Ck, BCHMC_K_FFT_R2C));
+    h->have_eval = false;
     return BCHMC_OK;
   }
-  if (!pre_za) CHK(launch_za(h, h->c.deltaQ_factor));
-  CHK(forward_rest(h, h->c.rsd_model));
-  CHK(like_force(h, like_mode));
-  double norm = -1.;  // zeldovich_norm, HMC_models.cc:458-461
-  norm *= h->c.deltaQ_factor;
-  if (h->c.correct_delta) norm *= h->c.D1;
-  *b = h->c.grad_psi_likeli_factor * norm;
-  return BCHMC_OK;
-}
 
-template <bool KICK>
-int launch_assemble(bchmc_handle *h, double a, double b, int like_mode, double c_kick, double *guard_slot,
-                    double2 *gk_out) {
-  ProfScope ps(h, BCHMC_K_KSPACE_FORCE_KICK);
-  k_assemble<KICK><<<nblk_stride(h->g.Nh), 256, 0, h->stream>>>(h->g, h->Ck, h->qk, h->wS, gk_out, h->pk, a, b,
-                                                                like_mode, c_kick, guard_slot, h->stop);
-  HIPCHK(hipGetLastError());
-  return BCHMC_OK;
-}
+  // Likelihood part of gradient_psi from the current q^: fills Ck, returns (like_mode, b).
+  // pre_za: Psi^ is already in Ck (the fused kick+drift+ZA kernel ran).
+  static int force_sources(bchmc_handle *h, bool pre_za, int *like_mode, double *b) {
+    if (h->c.likelihood == 3) {
+      CHK(grf_force(h));
+      *like_mode = 1;
+      *b = h->c.grad_psi_likeli_factor;
+      return BCHMC_OK;
+    }
+    if (!pre_za) CHK(launch_za(h, h->c.deltaQ_factor));
+    CHK(forward_rest(h, h->c.rsd_model));
+    CHK(like_force(h, like_mode));
+    double norm = -1.;  // zeldovich_norm, HMC_models.cc:458-461
+    norm *= h->c.deltaQ_factor;
+    if (h->c.correct_delta) norm *= h->c.D1;
+    *b = h->c.grad_psi_likeli_factor * norm;
+    return BCHMC_OK;
+  }
 
-int r2c_state(bchmc_handle *h, const double *d_real, double *staging, double2 *out) {
-  // rocFFT may use the input as scratch; transform from our own staging copy.
-  if (d_real != staging)
-    HIPCHK(hipMemcpyAsync(staging, d_real, h->g.N * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-  return fft_exec(h, h->r2c1, staging, out, BCHMC_K_FFT_R2C);
-}
-
-int c2r_state(bchmc_handle *h, const double2 *xk, double *d_out) {
-  {
-    ProfScope ps(h, BCHMC_K_OTHER);
-    k_scale_c<<<nblk_stride(h->g.Nh), 256, 0, h->stream>>>(h->g.Nh, xk, h->tC, 1. / (double)h->g.N);
+  template <bool KICK>
+  static int launch_assemble(bchmc_handle *h, double a, double b, int like_mode, double c_kick, double *guard_slot) {
+    ProfScope ps(h, BCHMC_K_KSPACE_FORCE_KICK);
+    k_assemble<T, KICK><<<nblk_stride(h->g.Nh), 256, 0, h->stream>>>(h->g, C(h->Ck), C(h->qk), h->wS, C(h->gk), C(h->pk),
+                                                                     a, b, like_mode, c_kick, guard_slot, h->stop);
     HIPCHK(hipGetLastError());
+    return BCHMC_OK;
   }
-  return fft_exec(h, h->c2r1, h->tC, d_out, BCHMC_K_FFT_C2R);
-}
 
-// extra = R2C[ C2R[p^]/N / mass_r ]  (real-space mass term of the drift, HMC.cc:317-327)
-int mass_rs_term(bchmc_handle *h) {
-  CHK(c2r_state(h, h->pk, h->iop));
-  {
-    ProfScope ps(h, BCHMC_K_OTHER);
-    k_div_mass_r<<<nblk_stride(h->g.N), 256, 0, h->stream>>>(h->g.N, h->iop, h->in_arr[BCHMC_F_MASS_R], h->iop);
-    HIPCHK(hipGetLastError());
+  // R2C of a real-space state given as an ABI (double) device array; `staging` receives the T copy that is
+  // transformed (rocFFT may use its input as scratch, and the caller's array must stay intact).
+  static int r2c_state(bchmc_handle *h, const double *d_real, void *staging, void *out) {
+    CHK(load_real(h, d_real, R(staging)));
+    return fft_exec(h, h->r2c1, staging, out, BCHMC_K_FFT_R2C);
   }
-  return fft_exec(h, h->r2c1, h->iop, h->tC, BCHMC_K_FFT_R2C);
-}
 
-int leapfrog_core(bchmc_handle *h, const double *d_q0, const double *d_p0, double *d_q1, double *d_p1, double eps,
-                  uint64_t neps) {
-  CHK(check_inputs(h, true));
-  if (eps > 2.) eps = 2.;  // HMC.cc:263-264
-  if (neps + 1 > h->guard_cap) {
-    if (h->guard) (void)hipFree(h->guard);
-    h->guard = nullptr;
-    h->guard_cap = std::max<size_t>(64, 2 * (neps + 1));
-    CHK(dev_alloc(h, &h->guard, h->guard_cap));
-  }
-  HIPCHK(hipMemsetAsync(h->guard, 0, (neps + 1) * sizeof(double), h->stream));
-  k_init_ctl<<<1, 1, 0, h->stream>>>(h->stop, h->steps_done, (unsigned long long)neps);
-  HIPCHK(hipGetLastError());
-
-  CHK(r2c_state(h, d_q0, h->ioq, h->qk));
-  CHK(r2c_state(h, d_p0, h->iop, h->pk));
-
-  const double a = h->c.grad_psi_prior_factor;
-  int like_mode = 2;
-  double b = 0.;
-  // 0) gradient at t = 0 (HMC.cc:279-280)
-  CHK(force_sources(h, false, &like_mode, &b));
-  CHK(launch_assemble<false>(h, a, b, like_mode, 0., nullptr, h->gk));
-
-  const bool fused_za = (h->c.likelihood != 3);
-  for (uint64_t s = 0; s < neps; s++) {
-    StepCtl ctl{h->stop, h->steps_done, s > 0 ? h->guard + (s - 1) : nullptr, 1e50 * (double)h->g.N, s};
-    const double c_za = -h->c.D1 * h->c.deltaQ_factor / (double)h->g.N;
-    if (!h->mass_rs) {
-      ProfScope ps(h, BCHMC_K_KSPACE_DRIFT_ZA);
-      k_kick_drift_za<true><<<nblk_stride(h->g.Nh), 256, 0, h->stream>>>(
-          h->g, h->qk, h->pk, h->gk, h->mass_fs ? h->wM : nullptr, nullptr, h->Ck, 0.5 * eps, eps, c_za, ctl);
-      HIPCHK(hipGetLastError());
-    } else {
-      // kick first (needs p in real space for the mass_r term), then drift with the extra term
-      {
-        ProfScope ps(h, BCHMC_K_KSPACE_DRIFT_ZA);
-        k_kick_drift_za<true><<<nblk_stride(h->g.Nh), 256, 0, h->stream>>>(h->g, h->qk, h->pk, h->gk, nullptr, nullptr,
-                                                                           h->Ck, 0.5 * eps, 0., c_za, ctl);
-        HIPCHK(hipGetLastError());
-      }
-      CHK(mass_rs_term(h));
-      StepCtl ctl2{h->stop, h->steps_done, nullptr, 0., s};
-      ProfScope ps(h, BCHMC_K_KSPACE_DRIFT_ZA);
-      k_kick_drift_za<true><<<nblk_stride(h->g.Nh), 256, 0, h->stream>>>(
-          h->g, h->qk, h->pk, h->gk, h->mass_fs ? h->wM : nullptr, h->tC, h->Ck, 0., eps, c_za, ctl2);
+  // xk / N -> C2R -> T array
+  static int c2r_scaled(bchmc_handle *h, const void *xk, void *out_T) {
+    {
+      ProfScope ps(h, BCHMC_K_OTHER);
+      k_scale_c<T><<<nblk_stride(h->g.Nh), 256, 0, h->stream>>>(h->g.Nh, reinterpret_cast<const CT *>(xk), C(h->tC),
+                                                                1. / (double)h->g.N);
       HIPCHK(hipGetLastError());
     }
-    CHK(force_sources(h, fused_za, &like_mode, &b));
-    CHK(launch_assemble<true>(h, a, b, like_mode, 0.5 * eps, h->guard + s, h->gk));
+    return fft_exec(h, h->c2r1, h->tC, out_T, BCHMC_K_FFT_C2R);
   }
-  CHK(c2r_state(h, h->qk, d_q1));
-  CHK(c2r_state(h, h->pk, d_p1));
-  return BCHMC_OK;
-}
 
-int energies_core(bchmc_handle *h, const double *d_q, const double *d_p, double out[3]) {
-  CHK(check_inputs(h, false));
-  const double N = (double)h->g.N;
-  CHK(r2c_state(h, d_q, h->ioq, h->qk));
-  CHK(r2c_state(h, d_p, h->iop, h->pk));
-  double kin = 0., v;
-  if (h->mass_fs) {
-    ProfScope ps(h, BCHMC_K_OTHER);
-    k_parseval<<<kRedBlocks, 256, 0, h->stream>>>(h->g, h->pk, h->wM, h->partA);
-    HIPCHK(hipGetLastError());
+  // C2R of a k-space state into an ABI (double) device array; `scratch_T` is used when T != double.
+  static int c2r_state(bchmc_handle *h, const void *xk, void *scratch_T, double *d_out) {
+    if (kDouble) return c2r_scaled(h, xk, d_out);
+    CHK(c2r_scaled(h, xk, scratch_T));
+    return store_real(h, R(scratch_T), d_out);
   }
-  if (h->mass_fs) {
+
+  // extra = R2C[ C2R[p^]/N / mass_r ]  (real-space mass term of the drift, HMC.cc:317-327)
+  static int mass_rs_term(bchmc_handle *h) {
+    CHK(c2r_scaled(h, h->pk, h->iop));
+    {
+      ProfScope ps(h, BCHMC_K_OTHER);
+      k_div_mass_r<T><<<nblk_stride(h->g.N), 256, 0, h->stream>>>(h->g.N, R(h->iop), R(h->in_arr[BCHMC_F_MASS_R]),
+                                                                  R(h->iop));
+      HIPCHK(hipGetLastError());
+    }
+    return fft_exec(h, h->r2c1, h->iop, h->tC, BCHMC_K_FFT_R2C);
+  }
+
+  static int leapfrog_core(bchmc_handle *h, const double *d_q0, const double *d_p0, double *d_q1, double *d_p1,
+                           double eps, uint64_t neps) {
+    CHK(check_inputs(h));
+    if (eps > 2.) eps = 2.;  // HMC.cc:263-264
+    if (neps + 1 > h->guard_cap) {
+      if (h->guard) (void)hipFree(h->guard);
+      h->guard = nullptr;
+      h->guard_cap = std::max<size_t>(64, 2 * (neps + 1));
+      CHK(dev_alloc(h, &h->guard, h->guard_cap));
+    }
+    HIPCHK(hipMemsetAsync(h->guard, 0, (neps + 1) * sizeof(double), h->stream));
+    k_init_ctl<<<1, 1, 0, h->stream>>>(h->stop, h->steps_done, (unsigned long long)neps);
+    HIPCHK(hipGetLastError());
+
+    CHK(r2c_state(h, d_q0, h->ioq, h->qk));
+    CHK(r2c_state(h, d_p0, h->iop, h->pk));
+
+    const double a = h->c.grad_psi_prior_factor;
+    int like_mode = 2;
+    double b = 0.;
+    // 0) gradient at t = 0 (HMC.cc:279-280)
+    CHK(force_sources(h, false, &like_mode, &b));
+    CHK(launch_assemble<false>(h, a, b, like_mode, 0., nullptr));
+
+    const bool fused_za = (h->c.likelihood != 3);
+    const double *wM = h->mass_fs ? h->wM : nullptr;
+    for (uint64_t s = 0; s < neps; s++) {
+      StepCtl ctl{h->stop, h->steps_done, s > 0 ? h->guard + (s - 1) : nullptr, 1e50 * (double)h->g.N, s};
+      const double c_za = -h->c.D1 * h->c.deltaQ_factor / (double)h->g.N;
+      if (!h->mass_rs) {
+        ProfScope ps(h, BCHMC_K_KSPACE_DRIFT_ZA);
+        k_kick_drift_za<T, true><<<nblk_stride(h->g.Nh), 256, 0, h->stream>>>(h->g, C(h->qk), C(h->pk), C(h->gk), wM,
+                                                                             nullptr, C(h->Ck), 0.5 * eps, eps, c_za, ctl);
+        HIPCHK(hipGetLastError());
+      } else {
+        // kick first (needs p in real space for the mass_r term), then drift with the extra term
+        {
+          ProfScope ps(h, BCHMC_K_KSPACE_DRIFT_ZA);
+          k_kick_drift_za<T, true><<<nblk_stride(h->g.Nh), 256, 0, h->stream>>>(
+              h->g, C(h->qk), C(h->pk), C(h->gk), nullptr, nullptr, C(h->Ck), 0.5 * eps, 0., c_za, ctl);
+          HIPCHK(hipGetLastError());
+        }
+        CHK(mass_rs_term(h));
+        StepCtl ctl2{h->stop, h->steps_done, nullptr, 0., s};
+        ProfScope ps(h, BCHMC_K_KSPACE_DRIFT_ZA);
+        k_kick_drift_za<T, true><<<nblk_stride(h->g.Nh), 256, 0, h->stream>>>(h->g, C(h->qk), C(h->pk), C(h->gk), wM,
+                                                                             C(h->tC), C(h->Ck), 0., eps, c_za, ctl2);
+        HIPCHK(hipGetLastError());
+      }
+      CHK(force_sources(h, fused_za, &like_mode, &b));
+      CHK(launch_assemble<true>(h, a, b, like_mode, 0.5 * eps, h->guard + s));
+    }
+    CHK(c2r_state(h, h->qk, h->ioq, d_q1));
+    CHK(c2r_state(h, h->pk, h->iop, d_p1));
+    return BCHMC_OK;
+  }
+
+  static int energies_core(bchmc_handle *h, const double *d_q, const double *d_p, double out[3]) {
+    CHK(check_inputs(h));
+    const double N = (double)h->g.N;
+    // keep real-space copies (T) for the real-space terms: rocFFT may clobber its input, so transform psi-scratch
+    // copies instead and keep ioq / iop intact
+    CHK(load_real(h, d_q, R(h->ioq)));
+    CHK(load_real(h, d_p, R(h->iop)));
+    T *scratch = R(h->psi);
+    HIPCHK(hipMemcpyAsync(scratch, h->ioq, h->g.N * sizeof(T), hipMemcpyDeviceToDevice, h->stream));
+    CHK(fft_exec(h, h->r2c1, scratch, h->qk, BCHMC_K_FFT_R2C));
+    HIPCHK(hipMemcpyAsync(scratch, h->iop, h->g.N * sizeof(T), hipMemcpyDeviceToDevice, h->stream));
+    CHK(fft_exec(h, h->r2c1, scratch, h->pk, BCHMC_K_FFT_R2C));
+    double kin = 0., v;
+    if (h->mass_fs) {
+      k_parseval<T><<<kRedBlocks, 256, 0, h->stream>>>(h->g, C(h->pk), h->wM, h->partA);
+      HIPCHK(hipGetLastError());
+      CHK(host_sum(h, h->partA, &v));
+      kin += v / (2. * N);
+    }
+    if (h->mass_rs) {
+      k_kin_rs<T><<<kRedBlocks, 256, 0, h->stream>>>(h->g.N, R(h->iop), R(h->in_arr[BCHMC_F_MASS_R]), h->partA);
+      HIPCHK(hipGetLastError());
+      CHK(host_sum(h, h->partA, &v));
+      kin += v;
+    }
+    k_parseval<T><<<kRedBlocks, 256, 0, h->stream>>>(h->g, C(h->qk), h->wS, h->partA);
+    HIPCHK(hipGetLastError());
     CHK(host_sum(h, h->partA, &v));
-    kin += v / (2. * N);
+    const double prior = v / (2. * N);
+    double like = 0.;
+    if (h->c.likelihood == 3) {
+      k_grf_loglike<T><<<kRedBlocks, 256, 0, h->stream>>>(h->g.N, R(h->ioq), R(h->in_arr[BCHMC_F_NOBS]),
+                                                          R(h->in_arr[BCHMC_F_NOISE]), R(h->in_arr[BCHMC_F_WINDOW]),
+                                                          h->partA);
+      HIPCHK(hipGetLastError());
+      CHK(host_sum(h, h->partA, &like));
+    } else {
+      // gaussian log_like applies deltaQ_factor and honours rsd_model (gaussian_independent.cpp:57-76);
+      // poissonian / log-normal log_like do neither (poissonian.cpp:54-56, lognormal_independent.cpp:105-107)
+      const bool gauss = (h->c.likelihood == 1);
+      CHK(launch_za(h, gauss ? h->c.deltaQ_factor : 1.));
+      CHK(forward_rest(h, gauss ? h->c.rsd_model : 0));
+      k_loglike<T><<<kRedBlocks, 256, 0, h->stream>>>(h->g, make_like(h), R(h->rho), h->rho_part,
+                                                      R(h->in_arr[BCHMC_F_NOBS]), R(h->in_arr[BCHMC_F_NOISE]),
+                                                      R(h->in_arr[BCHMC_F_WINDOW]), h->partA);
+      HIPCHK(hipGetLastError());
+      CHK(host_sum(h, h->partA, &like));
+    }
+    out[0] = kin;
+    out[1] = prior;
+    out[2] = like;
+    return BCHMC_OK;
   }
-  if (h->mass_rs) {
-    k_kin_rs<<<kRedBlocks, 256, 0, h->stream>>>(h->g.N, d_p, h->in_arr[BCHMC_F_MASS_R], h->partA);
-    HIPCHK(hipGetLastError());
-    CHK(host_sum(h, h->partA, &v));
-    kin += v;
+
+  static int forward(bchmc_handle *h, const double *d_q, int rsd) {
+    CHK(r2c_state(h, d_q, h->ioq, h->qk));
+    CHK(launch_za(h, 1.));
+    return forward_rest(h, rsd);
   }
-  k_parseval<<<kRedBlocks, 256, 0, h->stream>>>(h->g, h->qk, h->wS, h->partA);
-  HIPCHK(hipGetLastError());
-  CHK(host_sum(h, h->partA, &v));
-  const double prior = v / (2. * N);
-  double like = 0.;
-  if (h->c.likelihood == 3) {
-    k_grf_loglike<<<kRedBlocks, 256, 0, h->stream>>>(h->g.N, d_q, h->in_arr[BCHMC_F_NOBS], h->in_arr[BCHMC_F_NOISE],
-                                                     h->in_arr[BCHMC_F_WINDOW], h->partA);
+
+  static int gradient(bchmc_handle *h, const double *d_q, double *d_g) {
+    const size_t N = (size_t)h->g.N;
+    if (!h->gprior) {
+      CHK(dev_alloc_bytes(h, &h->gprior, N * sizeof(T)));
+      CHK(dev_alloc_bytes(h, &h->glike, N * sizeof(T)));
+    }
+    CHK(r2c_state(h, d_q, h->ioq, h->qk));
+    int like_mode = 2;
+    double b = 0.;
+    CHK(force_sources(h, false, &like_mode, &b));
+    CHK(launch_assemble<false>(h, h->c.grad_psi_prior_factor, 0., 2, 0., nullptr));
+    CHK(c2r_scaled(h, h->gk, h->gprior));
+    CHK(launch_assemble<false>(h, 0., b, like_mode, 0., nullptr));
+    CHK(c2r_scaled(h, h->gk, h->glike));
+    k_add_r<T><<<nblk_stride(h->g.N), 256, 0, h->stream>>>(h->g.N, R(h->gprior), R(h->glike), R(h->iop));
     HIPCHK(hipGetLastError());
-    CHK(host_sum(h, h->partA, &like));
-  } else {
-    // gaussian log_like applies deltaQ_factor and honours rsd_model (gaussian_independent.cpp:57-76);
-    // poissonian / log-normal log_like do neither (poissonian.cpp:54-56, lognormal_independent.cpp:105-107)
-    const bool gauss = (h->c.likelihood == 1);
-    CHK(launch_za(h, gauss ? h->c.deltaQ_factor : 1.));
-    CHK(forward_rest(h, gauss ? h->c.rsd_model : 0));
-    k_loglike<<<kRedBlocks, 256, 0, h->stream>>>(h->g, make_like(h), h->rho, h->rho_part, h->in_arr[BCHMC_F_NOBS],
-                                                 h->in_arr[BCHMC_F_NOISE], h->in_arr[BCHMC_F_WINDOW], h->partA);
-    HIPCHK(hipGetLastError());
-    CHK(host_sum(h, h->partA, &like));
+    return store_real(h, R(h->iop), d_g);
   }
-  out[0] = kin;
-  out[1] = prior;
-  out[2] = like;
-  return BCHMC_OK;
-}
+
+  // Fill the double staging array with one output field.
+  static int fetch(bchmc_handle *h, bchmc_field field, double *d_out) {
+    const size_t N = (size_t)h->g.N;
+    const T *src = nullptr;
+    switch (field) {
+      case BCHMC_F_SIGNAL_PS: case BCHMC_F_MASS_F: case BCHMC_F_MASS_R:
+      case BCHMC_F_NOBS: case BCHMC_F_NOISE: case BCHMC_F_WINDOW:
+        src = R(h->in_arr[field]);
+        break;
+      case BCHMC_F_DELTAX:
+        k_overdens<T><<<nblk_stride(h->g.N), 256, 0, h->stream>>>(h->g, R(h->rho), h->rho_part, R(h->ioq));
+        HIPCHK(hipGetLastError());
+        src = R(h->ioq);
+        break;
+      case BCHMC_F_POSX: case BCHMC_F_POSY: case BCHMC_F_POSZ:
+        k_positions<T><<<nblk_stride(h->g.N), 256, 0, h->stream>>>(h->g, make_pos(h, h->last_rsd), R(h->psi), R(h->ioq),
+                                                                   (int)field - (int)BCHMC_F_POSX);
+        HIPCHK(hipGetLastError());
+        src = R(h->ioq);
+        break;
+      case BCHMC_F_RHO: src = R(h->rho); break;
+      case BCHMC_F_PART_LIKE: src = R(h->plike); break;
+      case BCHMC_F_VX: case BCHMC_F_VY: case BCHMC_F_VZ: src = R(h->V) + ((int)field - (int)BCHMC_F_VX) * N; break;
+      case BCHMC_F_PSIX: case BCHMC_F_PSIY: case BCHMC_F_PSIZ: src = R(h->psi) + ((int)field - (int)BCHMC_F_PSIX) * N; break;
+      case BCHMC_F_GRAD_PRIOR: src = R(h->gprior); break;
+      case BCHMC_F_GRAD_LIKE: src = R(h->glike); break;
+      default: return h->fail(BCHMC_ERR_ARG, "unknown field %d", (int)field);
+    }
+    if (!src) return h->fail(BCHMC_ERR_STATE, "field %d has not been computed", (int)field);
+    return store_real(h, src, d_out);
+  }
+
+  static int upload(bchmc_handle *h, bchmc_field field, const double *d_src) {
+    CHK(load_real(h, d_src, R(h->in_arr[field])));
+    const double normFS = h->g.L * h->g.L * h->g.L / (double)h->g.N;  // FOURIER_DEF_2, HMC_help.cc:25-27
+    if (field == BCHMC_F_SIGNAL_PS || field == BCHMC_F_MASS_F) {
+      double *w = field == BCHMC_F_SIGNAL_PS ? h->wS : h->wM;
+      k_prepare_mult<<<nblk_stride(h->g.Nh), 256, 0, h->stream>>>(h->g, d_src, w, normFS);
+      HIPCHK(hipGetLastError());
+    }
+    return BCHMC_OK;
+  }
+};
+
+#define DISPATCH(h, call) ((h)->f32 ? Pipe<float>::call : Pipe<double>::call)
 
 int validate_config(const bchmc_config *c, std::string &why) {
   char buf[256];
@@ -662,9 +802,9 @@ int validate_config(const bchmc_config *c, std::string &why) {
     why = "Nx >= 4, L > 0 and particle_kernel_h > 0 are required";
     return BCHMC_ERR_ARG;
   }
-  if (c->precision != 0) {
-    why = "only precision 0 (fp64 fields) is built";
-    return BCHMC_ERR_UNSUPPORTED;
+  if (c->precision != 0 && c->precision != 1) {
+    why = "precision must be 0 (fp64 fields) or 1 (fp32 fields)";
+    return BCHMC_ERR_ARG;
   }
   if (c->likelihood < 0 || c->likelihood > 3) {
     why = "likelihood must be 0..3";
@@ -707,8 +847,9 @@ const char *bchmc_strerror(int code) {
 const char *bchmc_last_error(const bchmc_handle *h) { return h ? h->err.c_str() : ""; }
 
 const char *bchmc_kernel_name(int cls) {
-  static const char *names[BCHMC_K_COUNT] = {"rocfft_c2r", "rocfft_r2c",        "k_kick_drift_za", "k_scatter_sph",
-                                            "k_sum+k_partial_like", "k_gather_sph", "k_assemble", "k_bin+k_scan_tiles+k_reorder", "other"};
+  static const char *names[BCHMC_K_COUNT] = {"rocfft_c2r",   "rocfft_r2c",           "k_kick_drift_za",
+                                            "k_scatter_sph", "k_sum+k_partial_like", "k_gather_sph",
+                                            "k_assemble",    "k_bin+k_scan_tiles+k_reorder", "other"};
   return (cls >= 0 && cls < BCHMC_K_COUNT) ? names[cls] : "?";
 }
 
@@ -724,6 +865,8 @@ int bchmc_create(const bchmc_config *cfg, bchmc_handle **out) {
   int rc = validate_config(cfg, h->err);
   if (rc) return bail(rc);
   h->c = *cfg;
+  h->f32 = (cfg->precision == 1);
+  h->esz = h->f32 ? sizeof(float) : sizeof(double);
   switch (cfg->mass_type) {  // struct_hamil.h:272-313
     case 0: case 6: case 60: h->mass_rs = 1; h->mass_fs = 0; break;
     case 1: case 2: case 3: case 4: h->mass_rs = 0; h->mass_fs = 1; break;
@@ -747,14 +890,15 @@ int bchmc_create(const bchmc_config *cfg, bchmc_handle **out) {
       if (g_rocfft_users++ == 0) FFTCHK(rocfft_setup());
     }
     const size_t len[3] = {(size_t)g.n, (size_t)g.n, (size_t)g.n};  // fastest first; cubic
-    FFTCHK(rocfft_plan_create(&h->r2c1, rocfft_placement_notinplace, rocfft_transform_type_real_forward,
-                              rocfft_precision_double, 3, len, 1, nullptr));
-    FFTCHK(rocfft_plan_create(&h->c2r1, rocfft_placement_notinplace, rocfft_transform_type_real_inverse,
-                              rocfft_precision_double, 3, len, 1, nullptr));
-    FFTCHK(rocfft_plan_create(&h->r2c3, rocfft_placement_notinplace, rocfft_transform_type_real_forward,
-                              rocfft_precision_double, 3, len, 3, nullptr));
-    FFTCHK(rocfft_plan_create(&h->c2r3, rocfft_placement_notinplace, rocfft_transform_type_real_inverse,
-                              rocfft_precision_double, 3, len, 3, nullptr));
+    const rocfft_precision prec = h->f32 ? rocfft_precision_single : rocfft_precision_double;
+    FFTCHK(rocfft_plan_create(&h->r2c1, rocfft_placement_notinplace, rocfft_transform_type_real_forward, prec, 3, len, 1,
+                              nullptr));
+    FFTCHK(rocfft_plan_create(&h->c2r1, rocfft_placement_notinplace, rocfft_transform_type_real_inverse, prec, 3, len, 1,
+                              nullptr));
+    FFTCHK(rocfft_plan_create(&h->r2c3, rocfft_placement_notinplace, rocfft_transform_type_real_forward, prec, 3, len, 3,
+                              nullptr));
+    FFTCHK(rocfft_plan_create(&h->c2r3, rocfft_placement_notinplace, rocfft_transform_type_real_inverse, prec, 3, len, 3,
+                              nullptr));
     for (rocfft_plan p : {h->r2c1, h->c2r1, h->r2c3, h->c2r3}) {
       size_t wb = 0;
       FFTCHK(rocfft_plan_get_work_buffer_size(p, &wb));
@@ -766,28 +910,28 @@ int bchmc_create(const bchmc_config *cfg, bchmc_handle **out) {
       HIPCHK(hipMalloc(&h->work, h->work_bytes));
       FFTCHK(rocfft_execution_info_set_work_buffer(h->info, h->work, h->work_bytes));
     }
-    const size_t N = (size_t)g.N, Nh = (size_t)g.Nh;
-    for (int f = 0; f < 6; f++) CHK(dev_alloc(h, &h->in_arr[f], N));
+    const size_t N = (size_t)g.N, Nh = (size_t)g.Nh, e = h->esz;
+    for (int f = 0; f < 6; f++) CHK(dev_alloc_bytes(h, &h->in_arr[f], N * e));
     CHK(dev_alloc(h, &h->wS, Nh));
     CHK(dev_alloc(h, &h->wM, Nh));
-    CHK(dev_alloc(h, &h->qk, Nh));
-    CHK(dev_alloc(h, &h->pk, Nh));
-    CHK(dev_alloc(h, &h->gk, Nh));
-    CHK(dev_alloc(h, &h->Ck, 3 * Nh));
-    CHK(dev_alloc(h, &h->tC, Nh));
-    CHK(dev_alloc(h, &h->psi, 3 * N));
-    CHK(dev_alloc(h, &h->V, 3 * N));
-    CHK(dev_alloc(h, &h->rho, N));
-    CHK(dev_alloc(h, &h->plike, N));
-    CHK(dev_alloc(h, &h->ioq, N));
-    CHK(dev_alloc(h, &h->iop, N));
+    CHK(dev_alloc_bytes(h, &h->qk, 2 * Nh * e));
+    CHK(dev_alloc_bytes(h, &h->pk, 2 * Nh * e));
+    CHK(dev_alloc_bytes(h, &h->gk, 2 * Nh * e));
+    CHK(dev_alloc_bytes(h, &h->Ck, 3 * 2 * Nh * e));
+    CHK(dev_alloc_bytes(h, &h->tC, 2 * Nh * e));
+    CHK(dev_alloc_bytes(h, &h->psi, 3 * N * e));
+    CHK(dev_alloc_bytes(h, &h->V, 3 * N * e));
+    CHK(dev_alloc_bytes(h, &h->rho, N * e));
+    CHK(dev_alloc_bytes(h, &h->plike, N * e));
+    CHK(dev_alloc_bytes(h, &h->ioq, N * e));
+    CHK(dev_alloc_bytes(h, &h->iop, N * e));
+    CHK(dev_alloc(h, &h->dstage, 2 * N));
     CHK(dev_alloc(h, &h->rho_part, (size_t)kRedBlocks));
     CHK(dev_alloc(h, &h->partA, (size_t)kRedBlocks));
     CHK(dev_alloc(h, &h->stop, (size_t)1));
     CHK(dev_alloc(h, &h->steps_done, (size_t)1));
     HIPCHK(hipMemsetAsync(h->stop, 0, sizeof(int), h->stream));
     HIPCHK(hipHostMalloc((void **)&h->h_part, kRedBlocks * sizeof(double)));
-    // noise defaults to 1 so that likelihoods that never read it need no upload
     std::vector<int4> cols;
     build_hull(cfg->particle_kernel_h, g.d, cols, h->reach);
     h->hull_n = (int)cols.size();
@@ -796,7 +940,7 @@ int bchmc_create(const bchmc_config *cfg, bchmc_handle **out) {
       // getDensity_SPH visits the whole cube (massFunctions.cc:443-445); the hull may replace it only if every
       // cell outside the hull is farther than 2h from ANY point of the home cell (true for h = d).
       bool exact = true;
-      const double hh = cfg->particle_kernel_h, lim = 4. * hh * hh * (1. + 1e-9);
+      const double hh = cfg->particle_kernel_h, lim = 4. * hh * hh * (1. + 1e-4);
       for (int i1 = -h->reach; i1 <= h->reach; ++i1)
         for (int i2 = -h->reach; i2 <= h->reach; ++i2)
           for (int i3 = -h->reach; i3 <= h->reach; ++i3) {
@@ -804,7 +948,7 @@ int bchmc_create(const bchmc_config *cfg, bchmc_handle **out) {
             for (auto &c : cols)
               if (c.x == i1 && c.y == i2 && i3 >= c.z && i3 <= c.w) in_hull = true;
             if (in_hull) continue;
-            auto mind = [&](int i) { return std::max(std::abs(i) - 0.5 - 1e-9, 0.) * g.d; };  // home offset in [-d/2, d/2]
+            auto mind = [&](int i) { return std::max(std::abs(i) - 0.5 - 1e-4, 0.) * g.d; };  // home offset in [-d/2, d/2]
             const double m2 = mind(i1) * mind(i1) + mind(i2) * mind(i2) + mind(i3) * mind(i3);
             if (m2 <= lim) exact = false;
           }
@@ -832,16 +976,16 @@ int bchmc_create(const bchmc_config *cfg, bchmc_handle **out) {
         tp.ly = tp.ty + 2 * tp.R;
         tp.lz = tp.tz + 2 * tp.R;
         tp.chunk = 2048;
-        const size_t lds = (size_t)tp.lx * tp.ly * tp.lz * sizeof(double) + cols.size() * sizeof(int4) + 16;
+        const size_t lds = (size_t)tp.lx * tp.ly * tp.lz * sizeof(double) + cols.size() * sizeof(int4) + 128;
         if (lds <= 64 * 1024 && g.N < (1ll << 30)) {
           h->tiled = true;
           CHK(dev_alloc(h, &h->t_cnt, (size_t)tp.ntiles));
           CHK(dev_alloc(h, &h->t_off, (size_t)tp.ntiles + 1));
           CHK(dev_alloc(h, &h->t_woff, (size_t)tp.ntiles + 1));
           CHK(dev_alloc(h, &h->t_rank, N));
-          CHK(dev_alloc(h, &h->sx, N));
-          CHK(dev_alloc(h, &h->sy, N));
-          CHK(dev_alloc(h, &h->sz, N));
+          CHK(dev_alloc_bytes(h, &h->sx, N * e));
+          CHK(dev_alloc_bytes(h, &h->sy, N * e));
+          CHK(dev_alloc_bytes(h, &h->sz, N * e));
           CHK(dev_alloc(h, &h->sidx, N));
         }
       }
@@ -862,9 +1006,10 @@ void bchmc_destroy(bchmc_handle *h) {
   for (rocfft_plan p : {h->r2c1, h->c2r1, h->r2c3, h->c2r3})
     if (p) rocfft_plan_destroy(p);
   if (h->info) rocfft_execution_info_destroy(h->info);
-  void *ptrs[] = {h->work, h->wS,  h->wM,  h->qk,  h->pk,     h->gk,    h->Ck,       h->tC,    h->psi,  h->V,
-                  h->rho,  h->plike, h->ioq, h->iop, h->gprior, h->glike, h->rho_part, h->partA, h->guard, h->stop,
-                  h->steps_done, h->hull, h->conv, h->convF, h->t_cnt, h->t_off, h->t_woff, h->t_rank, h->sx, h->sy, h->sz, h->sidx};
+  void *ptrs[] = {h->work,  h->wS,       h->wM,    h->qk,    h->pk,   h->gk,     h->Ck,         h->tC,   h->psi,
+                  h->V,     h->rho,      h->plike, h->ioq,   h->iop,  h->gprior, h->glike,      h->conv, h->convF,
+                  h->dstage, h->rho_part, h->partA, h->guard, h->stop, h->steps_done, h->hull,  h->t_cnt, h->t_off,
+                  h->t_woff, h->t_rank,  h->sx,    h->sy,    h->sz,   h->sidx};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   for (int f = 0; f < 6; f++)
@@ -882,13 +1027,8 @@ int bchmc_upload(bchmc_handle *h, bchmc_field field, const double *host, size_t 
   if (!h || !host) return BCHMC_ERR_ARG;
   if ((int)field < 0 || (int)field > BCHMC_F_WINDOW) return h->fail(BCHMC_ERR_ARG, "field %d is not an input", (int)field);
   if (n != (size_t)h->g.N) return h->fail(BCHMC_ERR_ARG, "upload size %zu != N = %lld", n, h->g.N);
-  HIPCHK(hipMemcpyAsync(h->in_arr[field], host, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  const double normFS = h->g.L * h->g.L * h->g.L / (double)h->g.N;  // FOURIER_DEF_2, HMC_help.cc:25-27
-  if (field == BCHMC_F_SIGNAL_PS || field == BCHMC_F_MASS_F) {
-    double *w = field == BCHMC_F_SIGNAL_PS ? h->wS : h->wM;
-    k_prepare_mult<<<nblk_stride(h->g.Nh), 256, 0, h->stream>>>(h->g, h->in_arr[field], w, normFS);
-    HIPCHK(hipGetLastError());
-  }
+  HIPCHK(hipMemcpyAsync(h->dstage, host, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  CHK(DISPATCH(h, upload(h, field, h->dstage)));
   HIPCHK(hipStreamSynchronize(h->stream));
   h->have[field] = true;
   return BCHMC_OK;
@@ -905,7 +1045,7 @@ void *bchmc_stream(bchmc_handle *h) { return h ? (void *)h->stream : nullptr; }
 int bchmc_leapfrog_device(bchmc_handle *h, const double *d_q0, const double *d_p0, double *d_q1, double *d_p1,
                           double eps, uint64_t neps) {
   if (!h || !d_q0 || !d_p0 || !d_q1 || !d_p1) return BCHMC_ERR_ARG;
-  return leapfrog_core(h, d_q0, d_p0, d_q1, d_p1, eps, neps);
+  return DISPATCH(h, leapfrog_core(h, d_q0, d_p0, d_q1, d_p1, eps, neps));
 }
 
 int bchmc_steps_done(bchmc_handle *h, uint64_t *steps_done) {
@@ -920,13 +1060,13 @@ int bchmc_steps_done(bchmc_handle *h, uint64_t *steps_done) {
 int bchmc_leapfrog(bchmc_handle *h, const double *q0, const double *p0, double *q1, double *p1, double eps,
                    uint64_t neps, uint64_t *steps_done) {
   if (!h || !q0 || !p0 || !q1 || !p1) return BCHMC_ERR_ARG;
-  const size_t bytes = h->g.N * sizeof(double);
-  HIPCHK(hipMemcpyAsync(h->ioq, q0, bytes, hipMemcpyHostToDevice, h->stream));
-  HIPCHK(hipMemcpyAsync(h->iop, p0, bytes, hipMemcpyHostToDevice, h->stream));
-  // results land in psi[0..N) / psi[N..2N) (free once the last force evaluation is done)
-  CHK(leapfrog_core(h, h->ioq, h->iop, h->V, h->V + h->g.N, eps, neps));
-  HIPCHK(hipMemcpyAsync(q1, h->V, bytes, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipMemcpyAsync(p1, h->V + h->g.N, bytes, hipMemcpyDeviceToHost, h->stream));
+  const size_t N = (size_t)h->g.N, bytes = N * sizeof(double);
+  double *dq = h->dstage, *dp = h->dstage + N;
+  HIPCHK(hipMemcpyAsync(dq, q0, bytes, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(dp, p0, bytes, hipMemcpyHostToDevice, h->stream));
+  CHK(DISPATCH(h, leapfrog_core(h, dq, dp, dq, dp, eps, neps)));
+  HIPCHK(hipMemcpyAsync(q1, dq, bytes, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(p1, dp, bytes, hipMemcpyDeviceToHost, h->stream));
   uint64_t done = 0;
   CHK(bchmc_steps_done(h, &done));
   if (steps_done) *steps_done = done;
@@ -935,15 +1075,15 @@ int bchmc_leapfrog(bchmc_handle *h, const double *q0, const double *p0, double *
 
 int bchmc_energies_device(bchmc_handle *h, const double *d_q, const double *d_p, double out[3]) {
   if (!h || !d_q || !d_p || !out) return BCHMC_ERR_ARG;
-  return energies_core(h, d_q, d_p, out);
+  return DISPATCH(h, energies_core(h, d_q, d_p, out));
 }
 
 int bchmc_energies(bchmc_handle *h, const double *q, const double *p, double out[3]) {
   if (!h || !q || !p || !out) return BCHMC_ERR_ARG;
-  const size_t bytes = h->g.N * sizeof(double);
-  HIPCHK(hipMemcpyAsync(h->ioq, q, bytes, hipMemcpyHostToDevice, h->stream));
-  HIPCHK(hipMemcpyAsync(h->iop, p, bytes, hipMemcpyHostToDevice, h->stream));
-  return energies_core(h, h->ioq, h->iop, out);
+  const size_t N = (size_t)h->g.N, bytes = N * sizeof(double);
+  HIPCHK(hipMemcpyAsync(h->dstage, q, bytes, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->dstage + N, p, bytes, hipMemcpyHostToDevice, h->stream));
+  return DISPATCH(h, energies_core(h, h->dstage, h->dstage + N, out));
 }
 
 int bchmc_delta_hamiltonian(bchmc_handle *h, const double *qi, const double *pi, const double *qf, const double *pf,
@@ -963,34 +1103,19 @@ int bchmc_forward(bchmc_handle *h, const double *q, int use_rsd) {
   if (!h || !q) return BCHMC_ERR_ARG;
   if (h->c.likelihood == 3 && h->c.sfmodel != 1 && !h->c.rsd_model)
     return h->fail(BCHMC_ERR_UNSUPPORTED, "sfmodel != 1 forward model is not built");
-  HIPCHK(hipMemcpyAsync(h->ioq, q, h->g.N * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  CHK(r2c_state(h, h->ioq, h->ioq, h->qk));
-  CHK(launch_za(h, 1.));
-  CHK(forward_rest(h, use_rsd < 0 ? h->c.rsd_model : (use_rsd ? 1 : 0)));
+  HIPCHK(hipMemcpyAsync(h->dstage, q, h->g.N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  CHK(DISPATCH(h, forward(h, h->dstage, use_rsd < 0 ? h->c.rsd_model : (use_rsd ? 1 : 0))));
   HIPCHK(hipStreamSynchronize(h->stream));
   return BCHMC_OK;
 }
 
 int bchmc_gradient(bchmc_handle *h, const double *q, double *gout) {
   if (!h || !q || !gout) return BCHMC_ERR_ARG;
-  CHK(check_inputs(h, true));
+  CHK(check_inputs(h));
   const size_t N = (size_t)h->g.N;
-  if (!h->gprior) {
-    CHK(dev_alloc(h, &h->gprior, N));
-    CHK(dev_alloc(h, &h->glike, N));
-  }
-  HIPCHK(hipMemcpyAsync(h->ioq, q, N * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  CHK(r2c_state(h, h->ioq, h->ioq, h->qk));
-  int like_mode = 2;
-  double b = 0.;
-  CHK(force_sources(h, false, &like_mode, &b));
-  CHK(launch_assemble<false>(h, h->c.grad_psi_prior_factor, 0., 2, 0., nullptr, h->gk));
-  CHK(c2r_state(h, h->gk, h->gprior));
-  CHK(launch_assemble<false>(h, 0., b, like_mode, 0., nullptr, h->gk));
-  CHK(c2r_state(h, h->gk, h->glike));
-  k_add_r<<<nblk_stride(h->g.N), 256, 0, h->stream>>>(h->g.N, h->gprior, h->glike, h->iop);
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(gout, h->iop, N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(h->dstage, q, N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  CHK(DISPATCH(h, gradient(h, h->dstage, h->dstage + N)));
+  HIPCHK(hipMemcpyAsync(gout, h->dstage + N, N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   return BCHMC_OK;
 }
@@ -998,36 +1123,10 @@ int bchmc_gradient(bchmc_handle *h, const double *q, double *gout) {
 int bchmc_fetch(bchmc_handle *h, bchmc_field field, double *host, size_t n) {
   if (!h || !host) return BCHMC_ERR_ARG;
   if (n != (size_t)h->g.N) return h->fail(BCHMC_ERR_ARG, "fetch size %zu != N = %lld", n, h->g.N);
-  const size_t N = (size_t)h->g.N;
-  const double *src = nullptr;
   const bool needs_eval = (field >= BCHMC_F_DELTAX && field <= BCHMC_F_PSIZ);
   if (needs_eval && !h->have_eval) return h->fail(BCHMC_ERR_STATE, "no forward evaluation to fetch from");
-  switch (field) {
-    case BCHMC_F_SIGNAL_PS: case BCHMC_F_MASS_F: case BCHMC_F_MASS_R:
-    case BCHMC_F_NOBS: case BCHMC_F_NOISE: case BCHMC_F_WINDOW:
-      src = h->in_arr[field];
-      break;
-    case BCHMC_F_DELTAX:
-      k_overdens<<<nblk_stride(h->g.N), 256, 0, h->stream>>>(h->g, h->rho, h->rho_part, h->ioq);
-      HIPCHK(hipGetLastError());
-      src = h->ioq;
-      break;
-    case BCHMC_F_POSX: case BCHMC_F_POSY: case BCHMC_F_POSZ:
-      k_positions<<<nblk_stride(h->g.N), 256, 0, h->stream>>>(h->g, make_pos(h, h->last_rsd), h->psi, h->ioq,
-                                                              (int)field - (int)BCHMC_F_POSX);
-      HIPCHK(hipGetLastError());
-      src = h->ioq;
-      break;
-    case BCHMC_F_RHO: src = h->rho; break;
-    case BCHMC_F_PART_LIKE: src = h->plike; break;
-    case BCHMC_F_VX: case BCHMC_F_VY: case BCHMC_F_VZ: src = h->V + ((int)field - (int)BCHMC_F_VX) * N; break;
-    case BCHMC_F_PSIX: case BCHMC_F_PSIY: case BCHMC_F_PSIZ: src = h->psi + ((int)field - (int)BCHMC_F_PSIX) * N; break;
-    case BCHMC_F_GRAD_PRIOR: src = h->gprior; break;
-    case BCHMC_F_GRAD_LIKE: src = h->glike; break;
-    default: return h->fail(BCHMC_ERR_ARG, "unknown field %d", (int)field);
-  }
-  if (!src) return h->fail(BCHMC_ERR_STATE, "field %d has not been computed", (int)field);
-  HIPCHK(hipMemcpyAsync(host, src, N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  CHK(DISPATCH(h, fetch(h, field, h->dstage)));
+  HIPCHK(hipMemcpyAsync(host, h->dstage, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   return BCHMC_OK;
 }

@@ -7,6 +7,25 @@ namespace bchmc {
 
 constexpr int kWave = 64;  // CDNA wavefront width
 
+// Storage precision of the field arrays: T = double (reference DOUBLE_PREC) or float (BASELINE config 5).
+template <typename T> struct Vec2;
+template <> struct Vec2<double> { using type = double2; };
+template <> struct Vec2<float> { using type = float2; };
+template <typename T> using C2 = typename Vec2<T>::type;
+
+template <typename T>
+__device__ __forceinline__ double2 ld2(const C2<T> *p, long long i) {
+  const C2<T> v = p[i];
+  return make_double2((double)v.x, (double)v.y);
+}
+template <typename T>
+__device__ __forceinline__ void st2(C2<T> *p, long long i, double x, double y) {
+  C2<T> v;
+  v.x = (T)x;
+  v.y = (T)y;
+  p[i] = v;
+}
+
 // Geometry and scalars every kernel needs, passed by value (fits in SGPRs).
 struct Geo {
   int n;         // cells per axis
@@ -23,13 +42,23 @@ __device__ __forceinline__ double kval(int i, int n, double kfac) {
   return (i <= n / 2) ? kfac * (double)i : -kfac * (double)(n - i);
 }
 
+__device__ __forceinline__ double r_fmod(double a, double b) { return fmod(a, b); }
+__device__ __forceinline__ float r_fmod(float a, float b) { return fmodf(a, b); }
+__device__ __forceinline__ double r_floor(double a) { return floor(a); }
+__device__ __forceinline__ float r_floor(float a) { return floorf(a); }
+__device__ __forceinline__ double r_max(double a, double b) { return fmax(a, b); }
+__device__ __forceinline__ float r_max(float a, float b) { return fmaxf(a, b); }
+__device__ __forceinline__ double r_fma(double a, double b, double c) { return fma(a, b, c); }
+__device__ __forceinline__ float r_fma(float a, float b, float c) { return fmaf(a, b, c); }
+
 // pacman_coordinate, pacman.cpp:20-28
-__device__ __forceinline__ double pacman(double x, double L) {
-  if (x < 0.) {
-    x = fmod(x, L);
+template <typename T>
+__device__ __forceinline__ T pacman(T x, T L) {
+  if (x < T(0)) {
+    x = r_fmod(x, L);
     x += L;
   }
-  if (x >= L) x = fmod(x, L);
+  if (x >= L) x = r_fmod(x, L);
   return x;
 }
 
@@ -55,7 +84,31 @@ __device__ __forceinline__ double block_sum(double v, double *red) {
   return r;
 }
 
-// fp64 hardware atomic add (global_atomic_add_f64, no CAS loop); order-dependent in the last bits.
-__device__ __forceinline__ void atomic_add_f64(double *p, double v) { unsafeAtomicAdd(p, v); }
+// Hardware float atomics (global_atomic_add_f64 / _f32, ds_add_f64 / _f32; no CAS loop); order-dependent
+// in the last bits.
+__device__ __forceinline__ void atomic_add_r(double *p, double v) { unsafeAtomicAdd(p, v); }
+__device__ __forceinline__ void atomic_add_r(float *p, float v) { unsafeAtomicAdd(p, v); }
+
+// 1/sqrt(x) to ~1 ulp: hardware rsq seed + Newton steps.  Replaces the IEEE sqrt + divide pair of the
+// reference's kernel evaluations (about 35 fp64 instructions with range scaling and fix-ups); results differ
+// from the correctly rounded ones by <= 2 ulp, far inside the stated tolerance.  x must be positive and normal.
+__device__ __forceinline__ double fast_rsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  const double hx = 0.5 * x;
+  double e = fma(-hx * y, y, 0.5);
+  y = fma(y, e, y);
+  e = fma(-hx * y, y, 0.5);
+  y = fma(y, e, y);
+  return y;
+}
+__device__ __forceinline__ float fast_rsqrt(float x) {
+  float y = __builtin_amdgcn_rsqf(x);
+  const float e = fmaf(-0.5f * x * y, y, 0.5f);
+  return fmaf(y, e, y);
+}
+
+template <typename T> __device__ __forceinline__ T tiny_pos();
+template <> __device__ __forceinline__ double tiny_pos<double>() { return 1e-280; }
+template <> __device__ __forceinline__ float tiny_pos<float>() { return 1e-30f; }
 
 }  // namespace bchmc

@@ -1,19 +1,32 @@
-// kernels.hpp -- HIP kernels of the bchmc engine (gfx950 / CDNA4, wave64, fp64).
+// kernels.hpp -- HIP kernels of the bchmc engine (gfx950 / CDNA4, wave64).
 //
 // State lives in Fourier space: qk = R2C[q], pk = R2C[p] (unnormalised forward transforms, half-complex
 // n x n x (n/2+1), z fastest).  Everything that is diagonal in k (prior force S^-1 q, drift M^-1 p, the
 // Zel'dovich displacement kernel, the inverse-Laplacian-divergence of V, kicks) is done pointwise on those
 // arrays; only the particle-mesh part (displace, SPH scatter, likelihood partials, SPH-gradient gather)
 // runs in real space.  Reference lines restated by each kernel are cited at the kernel.
+//
+// Every kernel is a template on T, the STORAGE type of the field arrays (double = reference DOUBLE_PREC,
+// float = BASELINE config 5).  k-space arithmetic, k-vectors, reductions and the per-cell likelihood are always
+// done in double; the particle-mesh kernels (positions, spline evaluations, LDS accumulation) compute in T.
 #pragma once
 #include "common.hpp"
 
 namespace bchmc {
 
 // ------------------------------------------------------------------------------------------------------
+// Precision conversion for the C ABI (host arrays are always double, like the reference's default build).
+// ------------------------------------------------------------------------------------------------------
+template <typename A, typename B>
+__global__ void k_convert(long long n, const A *__restrict__ in, B *__restrict__ out) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    out[i] = (B)in[i];
+}
+
+// ------------------------------------------------------------------------------------------------------
 // Spectrum multipliers.  convolveInvCorrFuncWithSignal (HMC_help.cc:41-58) multiplies FFT[x] by
 // normFS / C(k) (0 where C <= 0) with C read from a FULL n^3 grid at index k + n*(j + n*i), k <= n/2.
-// We precompute that factor once per upload on the half-complex layout.
+// We precompute that factor once per upload on the half-complex layout (always double: it is a k-space weight).
 // ------------------------------------------------------------------------------------------------------
 __global__ void k_prepare_mult(Geo g, const double *__restrict__ corr, double *__restrict__ mult, double normFS) {
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < g.Nh;
@@ -34,6 +47,11 @@ struct StepCtl {
   unsigned long long step_index;    // number of completed steps if the guard fires now
 };
 
+__global__ void k_init_ctl(int *stop, unsigned long long *steps_done, unsigned long long neps) {
+  *stop = 0;
+  *steps_done = neps;
+}
+
 // ------------------------------------------------------------------------------------------------------
 // First half kick + drift + Zel'dovich displacement kernel, all diagonal in k:
 //   p^ -= eps/2 * g^                          HMC.cc:293-294
@@ -42,15 +60,10 @@ struct StepCtl {
 // c_za = -D1 * deltaQ_factor / N folds in the 1/N of the following C2R (fftwrapper.cc:99-101).
 // Psi^ is zero for k^2 <= 1e-14 and on every Nyquist plane.
 // ------------------------------------------------------------------------------------------------------
-__global__ void k_init_ctl(int *stop, unsigned long long *steps_done, unsigned long long neps) {
-  *stop = 0;
-  *steps_done = neps;
-}
-
-template <bool DRIFT>
+template <typename T, bool DRIFT>
 __global__ void __launch_bounds__(256)
-k_kick_drift_za(Geo g, double2 *__restrict__ qk, double2 *__restrict__ pk, const double2 *__restrict__ gk,
-                const double *__restrict__ wM, const double2 *__restrict__ extra, double2 *__restrict__ Ck,
+k_kick_drift_za(Geo g, C2<T> *__restrict__ qk, C2<T> *__restrict__ pk, const C2<T> *__restrict__ gk,
+                const double *__restrict__ wM, const C2<T> *__restrict__ extra, C2<T> *__restrict__ Ck,
                 double half_eps, double eps, double c_za, StepCtl ctl) {
   if (DRIFT) {
     if (*ctl.stop) return;
@@ -65,13 +78,13 @@ k_kick_drift_za(Geo g, double2 *__restrict__ qk, double2 *__restrict__ pk, const
   }
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < g.Nh;
        idx += (long long)gridDim.x * blockDim.x) {
-    double2 q = qk[idx];
+    double2 q = ld2<T>(qk, idx);
     if (DRIFT) {
-      double2 p = pk[idx];
-      const double2 gg = gk[idx];
+      double2 p = ld2<T>(pk, idx);
+      const double2 gg = ld2<T>(gk, idx);
       p.x -= half_eps * gg.x;
       p.y -= half_eps * gg.y;
-      pk[idx] = p;
+      st2<T>(pk, idx, p.x, p.y);
       double2 v = make_double2(0., 0.);
       if (wM) {
         const double w = wM[idx];
@@ -79,13 +92,13 @@ k_kick_drift_za(Geo g, double2 *__restrict__ qk, double2 *__restrict__ pk, const
         v.y = w * p.y;
       }
       if (extra) {
-        const double2 e = extra[idx];
+        const double2 e = ld2<T>(extra, idx);
         v.x += e.x;
         v.y += e.y;
       }
       q.x += eps * v.x;
       q.y += eps * v.y;
-      qk[idx] = q;
+      st2<T>(qk, idx, q.x, q.y);
     }
     const int k = (int)(idx % g.nh);
     const long long ij = idx / g.nh;
@@ -102,9 +115,9 @@ k_kick_drift_za(Geo g, double2 *__restrict__ qk, double2 *__restrict__ pk, const
       oy = make_double2(fy * pi, fy * -pr);
       oz = make_double2(fz * pi, fz * -pr);
     }
-    Ck[idx] = ox;
-    Ck[idx + g.Nh] = oy;
-    Ck[idx + 2 * g.Nh] = oz;
+    st2<T>(Ck, idx, ox.x, ox.y);
+    st2<T>(Ck, idx + g.Nh, oy.x, oy.y);
+    st2<T>(Ck, idx + 2 * g.Nh, oz.x, oz.y);
   }
 }
 
@@ -120,101 +133,106 @@ struct PosPar {
 // Compiled without FMA contraction: every kernel that calls this gets bit-identical positions (the sorted
 // path derives a particle's tile in one kernel and its LDS-local home cell in another), and the operation
 // sequence is the reference's (multiply, add, add, fmod) as its x86-64 build executes it.
-__device__ __forceinline__ void particle_pos(const PosPar &pp, int i, int j, int k, double psx, double psy,
-                                             double psz, double &x, double &y, double &z) {
+template <typename T>
+__device__ __forceinline__ void particle_pos(const PosPar &pp, int i, int j, int k, T psx, T psy, T psz, T &x, T &y,
+                                             T &z) {
 #pragma clang fp contract(off)
-  x = pp.d * (double)i + 0.5 * pp.d + psx;
-  y = pp.d * (double)j + 0.5 * pp.d + psy;
-  z = pp.d * (double)k + 0.5 * pp.d + psz;
+  const T d = (T)pp.d, L = (T)pp.L;
+  x = d * (T)i + T(0.5) * d + psx;
+  y = d * (T)j + T(0.5) * d + psy;
+  z = d * (T)k + T(0.5) * d + psz;
   if (pp.periodic) {
-    x = pacman(x, pp.L);
-    y = pacman(y, pp.L);
-    z = pacman(z, pp.L);
+    x = pacman(x, L);
+    y = pacman(y, L);
+    z = pacman(z, L);
   }
   if (pp.rsd) {
-    const double vz = pp.cpecvel * psz;
-    z = z + vz * pp.v_norm;
-    if (pp.periodic) z = pacman(z, pp.L);
+    const T vz = (T)pp.cpecvel * psz;
+    z = z + vz * (T)pp.v_norm;
+    if (pp.periodic) z = pacman(z, L);
   }
 }
 
-__global__ void k_positions(Geo g, PosPar pp, const double *__restrict__ psi, double *__restrict__ out, int comp) {
+template <typename T>
+__device__ __forceinline__ bool pos_ok(const Geo &g, T x, T y, T z) {
+  // false for non-finite positions (blown-up trajectory): those must never be used as indices
+  const T L = (T)g.L;
+  return x >= T(0) && x <= L && y >= T(0) && y <= L && z >= T(0) && z <= L;
+}
+
+template <typename T>
+__global__ void k_positions(Geo g, PosPar pp, const T *__restrict__ psi, T *__restrict__ out, int comp) {
   for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < g.N;
        p += (long long)gridDim.x * blockDim.x) {
     const int k = (int)(p % g.n);
     const long long ij = p / g.n;
     const int j = (int)(ij % g.n), i = (int)(ij / g.n);
-    double x, y, z;
-    particle_pos(pp, i, j, k, psi[p], psi[p + g.N], psi[p + 2 * g.N], x, y, z);
+    T x, y, z;
+    particle_pos<T>(pp, i, j, k, psi[p], psi[p + g.N], psi[p + 2 * g.N], x, y, z);
     out[p] = comp == 0 ? x : (comp == 1 ? y : z);
   }
 }
 
 // ------------------------------------------------------------------------------------------------------
 // SPH mass assignment (getDensity_SPH, massFunctions.cc:392-495; kernel W_4 at 366-384).
-// One thread per particle; visits the (2*reach+1)^3 cube like the reference and keeps its `r/h <= 2`
-// decision, but rejects columns/cells on squared distance before paying for sqrt and the atomic.
 // ------------------------------------------------------------------------------------------------------
 struct SphPar {
   double h, h_inv, w_norm;  // kernel scale, its inverse, 1/pi/h^3
-  double r2_lim;     // 4 h^2 (1 + 1e-12): beyond this r/h <= 2 cannot hold
+  double r2_lim;            // 4 h^2 (1 + 1e-12): beyond this r/h <= 2 cannot hold
   double min1, min2, min3;
   int reach;
 };
 
+// SPH_kernel_3D (massFunctions.cc:366-384), reference form
 __device__ __forceinline__ double sph_w(double q, double w_norm) {
-  // SPH_kernel_3D (massFunctions.cc:366-384)
   if (q <= 1.) return w_norm * (1 - 3. / 2 * q * q + 3. / 4 * q * q * q);
   const double t = 2. - q;
   return w_norm * (1. / 4 * (t * t * t));
 }
 
-// 1/sqrt(x) to ~1 ulp: hardware v_rsq_f64 seed (>= 26 good bits) + two Newton steps (7 FMAs).  Replaces the
-// IEEE sqrt + divide pair of the reference's kernel evaluations (about 35 fp64 instructions with range
-// scaling and fix-ups); results differ from the correctly rounded ones by <= 2 ulp, far inside the stated
-// fp64 tolerance.  x must be positive and normal.
-__device__ __forceinline__ double fast_rsqrt(double x) {
-  double y = __builtin_amdgcn_rsq(x);
-  const double hx = 0.5 * x;
-  double e = fma(-hx * y, y, 0.5);
-  y = fma(y, e, y);
-  e = fma(-hx * y, y, 0.5);
-  y = fma(y, e, y);
-  return y;
-}
-
 // W_4 (massFunctions.cc:366-384), branch-free; valid for 0 <= q <= 2.
-__device__ __forceinline__ double sph_w_sel(double q, double w_norm) {
-  const double inner = fma(q * q, fma(0.75, q, -1.5), 1.);  // 1 - 3/2 q^2 + 3/4 q^3
-  const double t = 2. - q;
-  const double outer = 0.25 * (t * t * t);
-  return w_norm * ((q <= 1.) ? inner : outer);
+template <typename T>
+__device__ __forceinline__ T sph_w_sel(T q, T w_norm) {
+  const T inner = r_fma(q * q, r_fma(T(0.75), q, T(-1.5)), T(1));  // 1 - 3/2 q^2 + 3/4 q^3
+  const T t = T(2) - q;
+  const T outer = T(0.25) * (t * t * t);
+  return w_norm * ((q <= T(1)) ? inner : outer);
 }
 
 // dW_4/dq / q in h units times `norm` (grad_SPH_kernel_3D_h_units, SPH_kernel.cpp:148-208), branch-free;
-// q_sq in (0, 4].  rq = 1/q.
-__device__ __forceinline__ double sph_grad_partial(double q_sq, double norm) {
-  const double rq = fast_rsqrt(fmax(q_sq, 1e-280));
-  const double q = q_sq * rq;
-  const double inner = (2.25 * q - 3.) * norm;
-  const double qm2 = q - 2.;
-  const double outer = (-0.75 * qm2 * qm2 * norm) * rq;
-  return (q_sq > 1.) ? outer : inner;
+// q_sq in (0, 4].
+template <typename T>
+__device__ __forceinline__ T sph_grad_partial(T q_sq, T norm) {
+  const T rq = fast_rsqrt(r_max(q_sq, tiny_pos<T>()));
+  const T q = q_sq * rq;
+  const T inner = (T(2.25) * q - T(3)) * norm;
+  const T qm2 = q - T(2);
+  const T outer = (T(-0.75) * qm2 * qm2 * norm) * rq;
+  return (q_sq > T(1)) ? outer : inner;
 }
 
+template <typename T>
+__device__ __forceinline__ bool in_domain(const Geo &g, const SphPar &sp, T x, T y, T z) {
+  // massFunctions.cc:426
+  const T L = (T)g.L, m1 = (T)sp.min1, m2 = (T)sp.min2, m3 = (T)sp.min3;
+  return (x >= m1 && x < m1 + L) && (y >= m2 && y < m2 + L) && (z >= m3 && z < m3 + L);
+}
+
+// Direct version: one thread per particle, global atomics (fallback when no tile shape divides the grid).
+// Visits the (2*reach+1)^3 cube like the reference and keeps its `r/h <= 2` decision, but rejects
+// columns/cells on squared distance before paying for sqrt and the atomic.
+template <typename T>
 __global__ void __launch_bounds__(256)
-k_scatter_sph(Geo g, PosPar pp, SphPar sp, const double *__restrict__ psi, double *__restrict__ rho) {
+k_scatter_sph(Geo g, PosPar pp, SphPar sp, const T *__restrict__ psi, T *__restrict__ rho) {
   const long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (p >= g.N) return;
   const int k = (int)(p % g.n);
   const long long ij = p / g.n;
   const int j = (int)(ij % g.n), i = (int)(ij / g.n);
-  double x, y, z;
-  particle_pos(pp, i, j, k, psi[p], psi[p + g.N], psi[p + 2 * g.N], x, y, z);
-  // domain test, massFunctions.cc:426
-  if (!((x >= sp.min1 && x < sp.min1 + g.L) && (y >= sp.min2 && y < sp.min2 + g.L) &&
-        (z >= sp.min3 && z < sp.min3 + g.L)))
-    return;
+  T xt, yt, zt;
+  particle_pos<T>(pp, i, j, k, psi[p], psi[p + g.N], psi[p + 2 * g.N], xt, yt, zt);
+  if (!in_domain(g, sp, xt, yt, zt)) return;
+  const double x = xt, y = yt, z = zt;
   const int n = g.n;
   const double d = g.d;
   const long long ix = (long long)(x / d), iy = (long long)(y / d), iz = (long long)(z / d);
@@ -230,7 +248,7 @@ k_scatter_sph(Geo g, PosPar pp, SphPar sp, const double *__restrict__ psi, doubl
       const double r2ab = dx2 + dy * dy;
       if (r2ab > sp.r2_lim) continue;
       const long long ky = (iy + i2 + (long long)n * 4) % n;
-      double *row = rho + (long long)n * (ky + (long long)n * kx);
+      T *row = rho + (long long)n * (ky + (long long)n * kx);
       for (int i3 = -R; i3 <= R; ++i3) {
         const double dz = z - (ccz + (double)i3 * d);
         const double r2 = r2ab + dz * dz;
@@ -239,7 +257,7 @@ k_scatter_sph(Geo g, PosPar pp, SphPar sp, const double *__restrict__ psi, doubl
         const double q = r / sp.h;
         if (q <= 2.) {
           const long long kz = (iz + i3 + (long long)n * 4) % n;
-          atomic_add_f64(row + kz, sph_w(q, sp.w_norm));
+          atomic_add_r(row + kz, (T)sph_w(q, sp.w_norm));
         }
       }
     }
@@ -247,15 +265,16 @@ k_scatter_sph(Geo g, PosPar pp, SphPar sp, const double *__restrict__ psi, doubl
 }
 
 // ------------------------------------------------------------------------------------------------------
-// Reductions
+// Reductions (always double)
 // ------------------------------------------------------------------------------------------------------
 constexpr int kRedBlocks = 1024;  // fixed partial count -> deterministic two-stage sums
 
-__global__ void __launch_bounds__(256) k_sum(const double *__restrict__ a, long long n, double *__restrict__ partials) {
+template <typename T>
+__global__ void __launch_bounds__(256) k_sum(const T *__restrict__ a, long long n, double *__restrict__ partials) {
   __shared__ double red[4];
   double s = 0.;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
-    s += a[i];
+    s += (double)a[i];
   s = block_sum(s, red);
   if (threadIdx.x == 0) partials[blockIdx.x] = s;
 }
@@ -285,69 +304,71 @@ __device__ __forceinline__ double pow_bias(double x, const LikePar &lp) {
   return lp.bias_is_identity ? x : pow(x, lp.biasE);
 }
 
+template <typename T>
 __global__ void __launch_bounds__(256)
-k_partial_like(Geo g, LikePar lp, const double *__restrict__ rho, const double *__restrict__ rho_partials,
-               const double *__restrict__ nobs, const double *__restrict__ noise, const double *__restrict__ window,
-               double *__restrict__ plike) {
+k_partial_like(Geo g, LikePar lp, const T *__restrict__ rho, const double *__restrict__ rho_partials,
+               const T *__restrict__ nobs, const T *__restrict__ noise, const T *__restrict__ window,
+               T *__restrict__ plike) {
   __shared__ double red[4];
   const double nmean = sum_partials(rho_partials, red) / (double)g.N;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < g.N;
        i += (long long)gridDim.x * blockDim.x) {
-    const double dX = rho[i] / nmean - 1.;
+    const double dX = (double)rho[i] / nmean - 1.;
     const double w = window[i];
     double out = 0.;
     if (lp.likelihood == 1) {
       const double Lambda = w * lp.rho_c * pow_bias(1. + lp.biasP * dX, lp);
       if ((w > 0.) && (Lambda > 0.0)) {
         const double s = noise[i];
-        out = (nobs[i] - Lambda) / (s * s);
+        out = ((double)nobs[i] - Lambda) / (s * s);
       }
     } else if (lp.likelihood == 0) {
       const double dens = 1. + lp.biasP * dX;
       if ((w > 0.0) && (dens > 0.0)) {
         const double Lambda = w * lp.rho_c * pow_bias(dens, lp);
         const double dpow = lp.bias_is_identity ? 1. : pow(dens, lp.biasE - 1);
-        out = (1 - nobs[i] / Lambda) * lp.rho_c * lp.biasE * lp.biasP * dpow;
+        out = (1 - (double)nobs[i] / Lambda) * lp.rho_c * lp.biasE * lp.biasP * dpow;
       }
     } else {  // 2: log-normal
       if (w > 0.) {
         const double Lambda = log(lp.rho_c * pow_bias(1. + lp.biasP * dX, lp));
         const double s = noise[i];
-        out = (nobs[i] - Lambda) / (s * s);
+        out = ((double)nobs[i] - Lambda) / (s * s);
       }
     }
-    plike[i] = out;
+    plike[i] = (T)out;
   }
 }
 
 // -log L per cell summed per block (gaussian_independent.cpp:82-89, poissonian.cpp:62-71,
 // lognormal_independent.cpp:111-121); the host adds the kRedBlocks partials.
+template <typename T>
 __global__ void __launch_bounds__(256)
-k_loglike(Geo g, LikePar lp, const double *__restrict__ rho, const double *__restrict__ rho_partials,
-          const double *__restrict__ nobs, const double *__restrict__ noise, const double *__restrict__ window,
+k_loglike(Geo g, LikePar lp, const T *__restrict__ rho, const double *__restrict__ rho_partials,
+          const T *__restrict__ nobs, const T *__restrict__ noise, const T *__restrict__ window,
           double *__restrict__ out_partials) {
   __shared__ double red[4];
   const double nmean = sum_partials(rho_partials, red) / (double)g.N;
   double acc = 0.;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < g.N;
        i += (long long)gridDim.x * blockDim.x) {
-    const double dX = rho[i] / nmean - 1.;
+    const double dX = (double)rho[i] / nmean - 1.;
     const double w = window[i];
     if (lp.likelihood == 1) {
       const double Lambda = w * lp.rho_c * pow_bias(1. + lp.biasP * dX, lp);
       if ((w > 0.) && (Lambda > 0.0)) {
-        const double t = (Lambda - nobs[i]) / noise[i];
+        const double t = (Lambda - (double)nobs[i]) / (double)noise[i];
         acc += 0.5 * (t * t);
       }
     } else if (lp.likelihood == 0) {
       const double Lambda = w * lp.rho_c * pow_bias(1. + lp.biasP * dX, lp);
-      if ((w > 0.) && (Lambda > 0.0)) acc += Lambda - nobs[i] * log(Lambda);
+      if ((w > 0.) && (Lambda > 0.0)) acc += Lambda - (double)nobs[i] * log(Lambda);
     } else {
       double dc = dX;
       if (dc < lp.delta_min) dc = lp.delta_min;
       const double Lambda = log(lp.rho_c * (1. + dc));
       if (w > 0.) {
-        const double resid = Lambda - nobs[i];
+        const double resid = Lambda - (double)nobs[i];
         const double s = noise[i];
         acc += 0.5 * resid * resid / (s * s);
       }
@@ -357,13 +378,14 @@ k_loglike(Geo g, LikePar lp, const double *__restrict__ rho, const double *__res
   if (threadIdx.x == 0) out_partials[blockIdx.x] = acc;
 }
 
+template <typename T>
 __global__ void __launch_bounds__(256)
-k_overdens(Geo g, const double *__restrict__ rho, const double *__restrict__ rho_partials, double *__restrict__ out) {
+k_overdens(Geo g, const T *__restrict__ rho, const double *__restrict__ rho_partials, T *__restrict__ out) {
   __shared__ double red[4];
   const double nmean = sum_partials(rho_partials, red) / (double)g.N;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < g.N;
        i += (long long)gridDim.x * blockDim.x)
-    out[i] = rho[i] / nmean - 1.;
+    out[i] = (T)((double)rho[i] / nmean - 1.);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -380,11 +402,12 @@ struct HullPar {
   double f1;               // fgrow(a), applied to V_z under RSD (HMC_models.cc:295-300)
 };
 
+// Direct version (fallback): one thread per particle, part_like read from global memory with periodic wrap.
+template <typename T>
 __global__ void __launch_bounds__(256)
-k_gather_sph(Geo g, PosPar pp, HullPar hp, const double *__restrict__ psi, const double *__restrict__ plike,
-             double *__restrict__ V) {
-  extern __shared__ int4 s_cols[];
-  for (int m = threadIdx.x; m < hp.ncol; m += blockDim.x) s_cols[m] = hp.cols[m];
+k_gather_sph(Geo g, PosPar pp, HullPar hp, const T *__restrict__ psi, const T *__restrict__ plike, T *__restrict__ V) {
+  extern __shared__ int4 s_cols_direct[];
+  for (int m = threadIdx.x; m < hp.ncol; m += blockDim.x) s_cols_direct[m] = hp.cols[m];
   __syncthreads();
   const long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (p >= g.N) return;
@@ -392,15 +415,16 @@ k_gather_sph(Geo g, PosPar pp, HullPar hp, const double *__restrict__ psi, const
   const int k = (int)(p % n);
   const long long ij = p / n;
   const int j = (int)(ij % n), i = (int)(ij / n);
-  double px, py, pz;
-  particle_pos(pp, i, j, k, psi[p], psi[p + g.N], psi[p + 2 * g.N], px, py, pz);
+  T xt, yt, zt;
+  particle_pos<T>(pp, i, j, k, psi[p], psi[p + g.N], psi[p + 2 * g.N], xt, yt, zt);
   // A non-finite position (blown-up trajectory) must not index out of bounds: such a particle gets V = 0.
-  if (!(px >= 0. && px <= g.L && py >= 0. && py <= g.L && pz >= 0. && pz <= g.L)) {
-    V[p] = 0.;
-    V[p + g.N] = 0.;
-    V[p + 2 * g.N] = 0.;
+  if (!pos_ok(g, xt, yt, zt)) {
+    V[p] = T(0);
+    V[p + g.N] = T(0);
+    V[p + 2 * g.N] = T(0);
     return;
   }
+  const double px = xt, py = yt, pz = zt;
   const int ix = (int)(px / g.d), iy = (int)(py / g.d), iz = (int)(pz / g.d);
   const double d_h = hp.d_h;
   const double dpcx = px * hp.h_inv - ((double)ix + 0.5) * d_h;
@@ -408,13 +432,13 @@ k_gather_sph(Geo g, PosPar pp, HullPar hp, const double *__restrict__ psi, const
   const double dpcz = pz * hp.h_inv - ((double)iz + 0.5) * d_h;
   double ox = 0., oy = 0., oz = 0.;
   for (int m = 0; m < hp.ncol; ++m) {
-    const int4 c = s_cols[m];
+    const int4 c = s_cols_direct[m];
     const double xh = dpcx - (double)c.x * d_h;
     const double yh = dpcy - (double)c.y * d_h;
     const double r2ab = xh * xh + yh * yh;
     if (r2ab > 4.) continue;  // q_sq > 4 -> zero gradient for the whole column
     const int kx = (ix + c.x + 4 * n) % n, ky = (iy + c.y + 4 * n) % n;
-    const double *row = plike + (long long)n * (ky + (long long)n * kx);
+    const T *row = plike + (long long)n * (ky + (long long)n * kx);
     double zh = dpcz - (double)c.z * d_h;
     for (int i3 = c.z; i3 <= c.w; ++i3) {
       const double q_sq = r2ab + zh * zh;
@@ -428,7 +452,7 @@ k_gather_sph(Geo g, PosPar pp, HullPar hp, const double *__restrict__ psi, const
           partial = (2.25 * q - 3.) * hp.norm;
         }
         const int kz = (iz + i3 + 4 * n) % n;
-        const double common = row[kz] * partial;
+        const double common = (double)row[kz] * partial;
         ox += common * xh;
         oy += common * yh;
         oz += common * zh;
@@ -440,9 +464,9 @@ k_gather_sph(Geo g, PosPar pp, HullPar hp, const double *__restrict__ psi, const
   oy *= hp.normalize;
   oz *= hp.normalize;
   if (pp.rsd) oz += hp.f1 * oz;
-  V[p] = ox;
-  V[p + g.N] = oy;
-  V[p + 2 * g.N] = oz;
+  V[p] = (T)ox;
+  V[p + g.N] = (T)oy;
+  V[p + 2 * g.N] = (T)oz;
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -450,13 +474,13 @@ k_gather_sph(Geo g, PosPar pp, HullPar hp, const double *__restrict__ psi, const
 //   h^ = sum_j (k_j/k^2) (Im V^_j, -Re V^_j), Nyquist planes and k = 0 -> 0   gradient.cpp:167-210
 //   g^ = a * wS * q^ + b * h^                                                  HMC.cc:170-173,205; HMC_models.cc:458-470
 //   p^ -= c * g^                                                               HMC.cc:351-352
-// like_mode 0: h^ from the three V^ (calc_h 2/3); 1: h^ = Ck[0] as is (calc_h 1, GRF); 2: no likelihood term.
+// like_mode 0: h^ from the three V^ (calc_h 0/2/3); 1: h^ = Ck[0] as is (calc_h 1, GRF); 2: no likelihood term.
 // The guard slot receives sum_k hw_k Re p^_k = N * p[0] (HMC.cc:360).
 // ------------------------------------------------------------------------------------------------------
-template <bool KICK>
+template <typename T, bool KICK>
 __global__ void __launch_bounds__(256)
-k_assemble(Geo g, const double2 *__restrict__ Ck, const double2 *__restrict__ qk, const double *__restrict__ wS,
-           double2 *__restrict__ gk, double2 *__restrict__ pk, double a, double b, int like_mode, double c_kick,
+k_assemble(Geo g, const C2<T> *__restrict__ Ck, const C2<T> *__restrict__ qk, const double *__restrict__ wS,
+           C2<T> *__restrict__ gk, C2<T> *__restrict__ pk, double a, double b, int like_mode, double c_kick,
            double *guard_slot, const int *stop) {
   __shared__ double red[4];
   if (KICK && *stop) return;
@@ -473,107 +497,112 @@ k_assemble(Geo g, const double2 *__restrict__ Ck, const double2 *__restrict__ qk
       const double kmod = kx * kx + ky * ky + kz * kz;
       if (kmod > 0 && !nyq) {
         const double f = 1 / kmod;
-        const double2 vx = Ck[idx], vy = Ck[idx + g.Nh], vz = Ck[idx + 2 * g.Nh];
+        const double2 vx = ld2<T>(Ck, idx), vy = ld2<T>(Ck, idx + g.Nh), vz = ld2<T>(Ck, idx + 2 * g.Nh);
         const double fx = kx * f, fy = ky * f, fz = kz * f;
         hk.x = fx * vx.y + fy * vy.y + fz * vz.y;
         hk.y = -(fx * vx.x) - fy * vy.x - fz * vz.x;
       }
     } else if (like_mode == 1) {
-      hk = Ck[idx];
+      hk = ld2<T>(Ck, idx);
     }
     double2 gg = make_double2(b * hk.x, b * hk.y);
     if (a != 0.) {
-      const double2 q = qk[idx];
+      const double2 q = ld2<T>(qk, idx);
       const double w = a * wS[idx];
       gg.x += w * q.x;
       gg.y += w * q.y;
     }
-    gk[idx] = gg;
+    st2<T>(gk, idx, gg.x, gg.y);
     if (KICK) {
-      double2 p = pk[idx];
+      double2 p = ld2<T>(pk, idx);
       p.x -= c_kick * gg.x;
       p.y -= c_kick * gg.y;
-      pk[idx] = p;
+      st2<T>(pk, idx, p.x, p.y);
       const double hw = (k == 0 || ((g.n & 1) == 0 && k == g.n / 2)) ? 1. : 2.;
       gsum += hw * p.x;
     }
   }
   if (KICK) {
     gsum = block_sum(gsum, red);
-    if (threadIdx.x == 0) atomic_add_f64(guard_slot, gsum);
+    if (threadIdx.x == 0) atomic_add_r(guard_slot, gsum);
   }
 }
 
 // sum_k hw_k * w_k * |x^_k|^2 per block: Parseval form of sum_x x * IFFT[w * FFT x]
 // (kinetic_term HMC.cc:101-115, prior_gaussian_log_prior gaussian.cpp:24-32).
+template <typename T>
 __global__ void __launch_bounds__(256)
-k_parseval(Geo g, const double2 *__restrict__ xk, const double *__restrict__ w, double *__restrict__ partials) {
+k_parseval(Geo g, const C2<T> *__restrict__ xk, const double *__restrict__ w, double *__restrict__ partials) {
   __shared__ double red[4];
   double s = 0.;
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < g.Nh;
        idx += (long long)gridDim.x * blockDim.x) {
     const int k = (int)(idx % g.nh);
     const double hw = (k == 0 || ((g.n & 1) == 0 && k == g.n / 2)) ? 1. : 2.;
-    const double2 x = xk[idx];
+    const double2 x = ld2<T>(xk, idx);
     s += hw * w[idx] * (x.x * x.x + x.y * x.y);
   }
   s = block_sum(s, red);
   if (threadIdx.x == 0) partials[blockIdx.x] = s;
 }
 
-__global__ void k_scale_c(long long n, const double2 *__restrict__ in, double2 *__restrict__ out, double s) {
+template <typename T>
+__global__ void k_scale_c(long long n, const C2<T> *__restrict__ in, C2<T> *__restrict__ out, double s) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-    const double2 v = in[i];
-    out[i] = make_double2(v.x * s, v.y * s);
+    const double2 v = ld2<T>(in, i);
+    st2<T>(out, i, v.x * s, v.y * s);
   }
 }
 
-__global__ void k_add_r(long long n, const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ out) {
+template <typename T>
+__global__ void k_add_r(long long n, const T *__restrict__ a, const T *__restrict__ b, T *__restrict__ out) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
     out[i] = a[i] + b[i];
 }
 
 // Real-space mass term: t = p / mass_r (0 where mass_r <= 0), HMC.cc:317-327.
-__global__ void k_div_mass_r(long long n, const double *__restrict__ p, const double *__restrict__ mass_r,
-                             double *__restrict__ out) {
+template <typename T>
+__global__ void k_div_mass_r(long long n, const T *__restrict__ p, const T *__restrict__ mass_r, T *__restrict__ out) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     const double m = mass_r[i];
-    out[i] = (m > 0.0) ? p[i] * (1. / m) : 0.;
+    out[i] = (m > 0.0) ? (T)((double)p[i] * (1. / m)) : T(0);
   }
 }
 
 // sum 0.5 * p * (p / mass_r): real-space part of kinetic_term (HMC.cc:88-110)
+template <typename T>
 __global__ void __launch_bounds__(256)
-k_kin_rs(long long n, const double *__restrict__ p, const double *__restrict__ mass_r, double *__restrict__ partials) {
+k_kin_rs(long long n, const T *__restrict__ p, const T *__restrict__ mass_r, double *__restrict__ partials) {
   __shared__ double red[4];
   double s = 0.;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-    const double m = mass_r[i];
+    const double m = mass_r[i], pv = p[i];
     const double invM = (m > 0.0) ? 1. / m : 0.;
-    s += 0.5 * p[i] * (invM * p[i]);
+    s += 0.5 * pv * (invM * pv);
   }
   s = block_sum(s, red);
   if (threadIdx.x == 0) partials[blockIdx.x] = s;
 }
 
 // GRF likelihood (gaussian_random_field.cpp:25-52): force (q - nobs)/sigma^2 and energy, window-masked.
-__global__ void k_grf_grad(long long n, const double *__restrict__ q, const double *__restrict__ nobs,
-                           const double *__restrict__ noise, const double *__restrict__ window,
-                           double *__restrict__ out) {
+template <typename T>
+__global__ void k_grf_grad(long long n, const T *__restrict__ q, const T *__restrict__ nobs, const T *__restrict__ noise,
+                           const T *__restrict__ window, T *__restrict__ out) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     const double s = noise[i];
-    out[i] = (window[i] > 0.) ? (q[i] - nobs[i]) / (s * s) : 0.;
+    out[i] = ((double)window[i] > 0.) ? (T)(((double)q[i] - (double)nobs[i]) / (s * s)) : T(0);
   }
 }
 
+template <typename T>
 __global__ void __launch_bounds__(256)
-k_grf_loglike(long long n, const double *__restrict__ q, const double *__restrict__ nobs,
-              const double *__restrict__ noise, const double *__restrict__ window, double *__restrict__ partials) {
+k_grf_loglike(long long n, const T *__restrict__ q, const T *__restrict__ nobs, const T *__restrict__ noise,
+              const T *__restrict__ window, double *__restrict__ partials) {
   __shared__ double red[4];
   double s = 0.;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
-    if (window[i] > 0.) {
-      const double t = (q[i] - nobs[i]) / noise[i];
+    if ((double)window[i] > 0.) {
+      const double t = ((double)q[i] - (double)nobs[i]) / (double)noise[i];
       s += 0.5 * (t * t);
     }
   s = block_sum(s, red);
@@ -583,19 +612,21 @@ k_grf_loglike(long long n, const double *__restrict__ q, const double *__restric
 // ------------------------------------------------------------------------------------------------------
 // NGP / CIC / TSC mass assignment (forward model only: getDensity_NGP massFunctions.cc:49-98,
 // getDensity_CIC :100-164 with getCICcells/getCICweights interpolate_grid.cpp:27-79, getDensity_TSC :167-364).
-// One thread per particle, 1 / 8 / 27 global fp64 atomics.  Index and weight formulas are the reference's,
+// One thread per particle, 1 / 8 / 27 global atomics.  Index and weight formulas are the reference's,
 // including the cell-centred CIC shift (x - d/2 wrapped) and TSC's inclusive `<= min + L` domain test.
 // ------------------------------------------------------------------------------------------------------
+template <typename T>
 __global__ void __launch_bounds__(256)
-k_scatter_low_order(Geo g, PosPar pp, SphPar sp, int mk, const double *__restrict__ psi, double *__restrict__ rho) {
+k_scatter_low_order(Geo g, PosPar pp, SphPar sp, int mk, const T *__restrict__ psi, T *__restrict__ rho) {
   const long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (p >= g.N) return;
   const int n = g.n;
   const int k = (int)(p % n);
   const long long ij = p / n;
   const int j = (int)(ij % n), i = (int)(ij / n);
-  double x, y, z;
-  particle_pos(pp, i, j, k, psi[p], psi[p + g.N], psi[p + 2 * g.N], x, y, z);
+  T xt, yt, zt;
+  particle_pos<T>(pp, i, j, k, psi[p], psi[p + g.N], psi[p + 2 * g.N], xt, yt, zt);
+  const double x = xt, y = yt, z = zt;
   const double d = g.d, L = g.L;
   if (mk == 2) {
     if (!((x >= sp.min1 && x <= sp.min1 + L) && (y >= sp.min2 && y <= sp.min2 + L) && (z >= sp.min3 && z <= sp.min3 + L)))
@@ -604,10 +635,11 @@ k_scatter_low_order(Geo g, PosPar pp, SphPar sp, int mk, const double *__restric
     if (!((x >= sp.min1 && x < sp.min1 + L) && (y >= sp.min2 && y < sp.min2 + L) && (z >= sp.min3 && z < sp.min3 + L)))
       return;
   }
+#define RHO_AT(a, b, c) (rho + (c) + (long long)n * ((b) + (long long)n * (a)))
   if (mk == 0) {
     const unsigned ci = (unsigned)floor((x - sp.min1) / d) % n, cj = (unsigned)floor((y - sp.min2) / d) % n,
                    ck = (unsigned)floor((z - sp.min3) / d) % n;
-    atomic_add_f64(rho + ck + (long long)n * (cj + (long long)n * ci), 1.);
+    atomic_add_r(RHO_AT(ci, cj, ck), T(1));
   } else if (mk == 1) {
     double q[3] = {x - 0.5 * d, y - 0.5 * d, z - 0.5 * d};
     long long c1[3], c2[3];
@@ -622,15 +654,14 @@ k_scatter_low_order(Geo g, PosPar pp, SphPar sp, int mk, const double *__restric
       tx[a] = 1. - dx[a];
     }
     const double mass = 1.;
-#define RHO_AT(a, b, c) (rho + (c) + (long long)n * ((b) + (long long)n * (a)))
-    atomic_add_f64(RHO_AT(c1[0], c1[1], c1[2]), mass * tx[0] * tx[1] * tx[2]);
-    atomic_add_f64(RHO_AT(c2[0], c1[1], c1[2]), mass * dx[0] * tx[1] * tx[2]);
-    atomic_add_f64(RHO_AT(c1[0], c2[1], c1[2]), mass * tx[0] * dx[1] * tx[2]);
-    atomic_add_f64(RHO_AT(c1[0], c1[1], c2[2]), mass * tx[0] * tx[1] * dx[2]);
-    atomic_add_f64(RHO_AT(c2[0], c2[1], c1[2]), mass * dx[0] * dx[1] * tx[2]);
-    atomic_add_f64(RHO_AT(c2[0], c1[1], c2[2]), mass * dx[0] * tx[1] * dx[2]);
-    atomic_add_f64(RHO_AT(c1[0], c2[1], c2[2]), mass * tx[0] * dx[1] * dx[2]);
-    atomic_add_f64(RHO_AT(c2[0], c2[1], c2[2]), mass * dx[0] * dx[1] * dx[2]);
+    atomic_add_r(RHO_AT(c1[0], c1[1], c1[2]), (T)(mass * tx[0] * tx[1] * tx[2]));
+    atomic_add_r(RHO_AT(c2[0], c1[1], c1[2]), (T)(mass * dx[0] * tx[1] * tx[2]));
+    atomic_add_r(RHO_AT(c1[0], c2[1], c1[2]), (T)(mass * tx[0] * dx[1] * tx[2]));
+    atomic_add_r(RHO_AT(c1[0], c1[1], c2[2]), (T)(mass * tx[0] * tx[1] * dx[2]));
+    atomic_add_r(RHO_AT(c2[0], c2[1], c1[2]), (T)(mass * dx[0] * dx[1] * tx[2]));
+    atomic_add_r(RHO_AT(c2[0], c1[1], c2[2]), (T)(mass * dx[0] * tx[1] * dx[2]));
+    atomic_add_r(RHO_AT(c1[0], c2[1], c2[2]), (T)(mass * tx[0] * dx[1] * dx[2]));
+    atomic_add_r(RHO_AT(c2[0], c2[1], c2[2]), (T)(mass * dx[0] * dx[1] * dx[2]));
   } else {
     const double pos[3] = {(x - sp.min1) / d, (y - sp.min2) / d, (z - sp.min3) / d};
     unsigned c[3][3];
@@ -651,9 +682,9 @@ k_scatter_low_order(Geo g, PosPar pp, SphPar sp, int mk, const double *__restric
 #pragma unroll
       for (int b = 0; b < 3; b++)
 #pragma unroll
-        for (int e = 0; e < 3; e++) atomic_add_f64(RHO_AT(c[0][a], c[1][b], c[2][e]), 1. * w[0][a] * w[1][b] * w[2][e]);
-#undef RHO_AT
+        for (int e = 0; e < 3; e++) atomic_add_r(RHO_AT(c[0][a], c[1][b], c[2][e]), (T)(1. * w[0][a] * w[1][b] * w[2][e]));
   }
+#undef RHO_AT
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -665,8 +696,9 @@ k_scatter_low_order(Geo g, PosPar pp, SphPar sp, int mk, const double *__restric
 // tabulated once per handle on the HOST with the C library (bchmc.hip: build_conv_table), which keeps the engine
 // on the same values as a CPU build of the reference and keeps sin/cos out of the step loop.
 // ------------------------------------------------------------------------------------------------------
+template <typename T>
 __global__ void __launch_bounds__(256)
-k_conv_kernel(Geo g, const double2 *__restrict__ pl, const double *__restrict__ F, double2 *__restrict__ Ck, double hh,
+k_conv_kernel(Geo g, const C2<T> *__restrict__ pl, const double *__restrict__ F, C2<T> *__restrict__ Ck, double hh,
               double inv_n) {
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < g.Nh;
        idx += (long long)gridDim.x * blockDim.x) {
@@ -675,33 +707,34 @@ k_conv_kernel(Geo g, const double2 *__restrict__ pl, const double *__restrict__ 
     const int j = (int)(ij % g.n), i = (int)(ij / g.n);
     const double kx = kval(i, g.n, g.kfac), ky = kval(j, g.n, g.kfac), kz = kval(k, g.n, g.kfac);
     const double f = F[idx];
-    const double2 v = pl[idx];
+    const double2 v = ld2<T>(pl, idx);
     // re = h * k_j * -Im(pl) * F, im = h * k_j * Re(pl) * F  (HMC_models_testing.cpp:117-130), then / N
-    Ck[idx] = make_double2(hh * kx * -v.y * f * inv_n, hh * kx * v.x * f * inv_n);
-    Ck[idx + g.Nh] = make_double2(hh * ky * -v.y * f * inv_n, hh * ky * v.x * f * inv_n);
-    Ck[idx + 2 * g.Nh] = make_double2(hh * kz * -v.y * f * inv_n, hh * kz * v.x * f * inv_n);
+    st2<T>(Ck, idx, hh * kx * -v.y * f * inv_n, hh * kx * v.x * f * inv_n);
+    st2<T>(Ck, idx + g.Nh, hh * ky * -v.y * f * inv_n, hh * ky * v.x * f * inv_n);
+    st2<T>(Ck, idx + 2 * g.Nh, hh * kz * -v.y * f * inv_n, hh * kz * v.x * f * inv_n);
   }
 }
 
 // TSC interpolation of the three convolved fields to every particle.  Bug-for-bug with the reference:
 // the upper weights of x and y are computed from dz (interpolate_grid.cpp:166-168).
+template <typename T>
 __global__ void __launch_bounds__(256)
-k_interp_tsc(Geo g, PosPar pp, double f1, const double *__restrict__ psi, const double *__restrict__ conv,
-             double *__restrict__ V) {
+k_interp_tsc(Geo g, PosPar pp, double f1, const T *__restrict__ psi, const T *__restrict__ conv, T *__restrict__ V) {
   const long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (p >= g.N) return;
   const int n = g.n;
   const int k = (int)(p % n);
   const long long ij = p / n;
   const int j = (int)(ij % n), i = (int)(ij / n);
-  double x, y, z;
-  particle_pos(pp, i, j, k, psi[p], psi[p + g.N], psi[p + 2 * g.N], x, y, z);
-  if (!(x >= 0. && x <= g.L && y >= 0. && y <= g.L && z >= 0. && z <= g.L)) {
-    V[p] = 0.;
-    V[p + g.N] = 0.;
-    V[p + 2 * g.N] = 0.;
+  T xt, yt, zt;
+  particle_pos<T>(pp, i, j, k, psi[p], psi[p + g.N], psi[p + 2 * g.N], xt, yt, zt);
+  if (!pos_ok(g, xt, yt, zt)) {
+    V[p] = T(0);
+    V[p + g.N] = T(0);
+    V[p + 2 * g.N] = T(0);
     return;
   }
+  const double x = xt, y = yt, z = zt;
   const double xk = x / g.d, yk = y / g.d, zk = z / g.d;
   const unsigned cx = (unsigned)xk, cy = (unsigned)yk, cz = (unsigned)zk;
   const double dx = xk - ((double)cx + 0.5), dy = yk - ((double)cy + 0.5), dz = zk - ((double)cz + 0.5);
@@ -726,14 +759,14 @@ k_interp_tsc(Geo g, PosPar pp, double f1, const double *__restrict__ psi, const 
       for (int c = 0; c < 3; ++c) {
         const long long f = ((long long)ixx[a] * n + ixy[b]) * n + ixz[c];
         const double w = wx[a] * wy[b] * wz[c];
-        o0 += w * conv[f];
-        o1 += w * conv[f + g.N];
-        o2 += w * conv[f + 2 * g.N];
+        o0 += w * (double)conv[f];
+        o1 += w * (double)conv[f + g.N];
+        o2 += w * (double)conv[f + 2 * g.N];
       }
   if (pp.rsd) o2 += f1 * o2;
-  V[p] = o0;
-  V[p + g.N] = o1;
-  V[p + 2 * g.N] = o2;
+  V[p] = (T)o0;
+  V[p + g.N] = (T)o1;
+  V[p + 2 * g.N] = (T)o2;
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -741,33 +774,40 @@ k_interp_tsc(Geo g, PosPar pp, double f1, const double *__restrict__ psi, const 
 // V_j = part_like * d f(delta_x)/dx_j with the gradient taken spectrally for the Gaussian likelihood (gradfft,
 // gradient.cpp:22-78) and by 4th-order central differences otherwise (gradfindif, gradient.cpp:81-154).
 // ------------------------------------------------------------------------------------------------------
+template <typename T>
 __global__ void __launch_bounds__(256)
-k_gradfft_mult(Geo g, const double2 *__restrict__ fk, double2 *__restrict__ Ck, double inv_n) {
+k_gradfft_mult(Geo g, const C2<T> *__restrict__ fk, C2<T> *__restrict__ Ck, double inv_n) {
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < g.Nh;
        idx += (long long)gridDim.x * blockDim.x) {
     const int k = (int)(idx % g.nh);
     const long long ij = idx / g.nh;
     const int j = (int)(ij % g.n), i = (int)(ij / g.n);
     const bool nyq = (i == g.n / 2) || (j == g.n / 2) || (k == g.n / 2);
-    const double2 v = fk[idx];
+    const double2 v = ld2<T>(fk, idx);
     const double kk[3] = {kval(i, g.n, g.kfac), kval(j, g.n, g.kfac), kval(k, g.n, g.kfac)};
 #pragma unroll
-    for (int c = 0; c < 3; c++)
-      Ck[idx + c * g.Nh] = nyq ? make_double2(0., 0.) : make_double2(-kk[c] * v.y * inv_n, kk[c] * v.x * inv_n);
+    for (int c = 0; c < 3; c++) {
+      if (nyq)
+        st2<T>(Ck, idx + c * g.Nh, 0., 0.);
+      else
+        st2<T>(Ck, idx + c * g.Nh, -kk[c] * v.y * inv_n, kk[c] * v.x * inv_n);
+    }
   }
 }
 
-__global__ void k_mul3(long long n, const double *__restrict__ a, const double *__restrict__ b3, double *__restrict__ out3) {
+template <typename T>
+__global__ void k_mul3(long long n, const T *__restrict__ a, const T *__restrict__ b3, T *__restrict__ out3) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-    const double v = a[i];
+    const T v = a[i];
     out3[i] = v * b3[i];
     out3[i + n] = v * b3[i + n];
     out3[i + 2 * n] = v * b3[i + 2 * n];
   }
 }
 
+template <typename T>
 __global__ void __launch_bounds__(256)
-k_findif_mul(Geo g, LikePar lp, const double *__restrict__ dX, const double *__restrict__ plike, double *__restrict__ V) {
+k_findif_mul(Geo g, LikePar lp, const T *__restrict__ dX, const T *__restrict__ plike, T *__restrict__ V) {
   const int n = g.n;
   const double fac = n / (2. * g.L);
   for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < g.N; p += (long long)gridDim.x * blockDim.x) {
@@ -788,7 +828,7 @@ k_findif_mul(Geo g, LikePar lp, const double *__restrict__ dX, const double *__r
         }
         f[m] = v;
       }
-      V[p + a * g.N] = pl * -(fac * ((4.0 / 3) * (f[0] - f[1]) - (1.0 / 6) * (f[2] - f[3])));
+      V[p + a * g.N] = (T)(pl * -(fac * ((4.0 / 3) * (f[0] - f[1]) - (1.0 / 6) * (f[2] - f[3]))));
     }
   }
 }
@@ -799,19 +839,20 @@ k_findif_mul(Geo g, LikePar lp, const double *__restrict__ dX, const double *__r
 // Zel'dovich displacements at the BASELINE resolution are many cells long (rms 3-10 cells at 256^3 in a
 // 200 Mpc/h box), so a Lagrangian brick of particles does NOT stay inside an LDS-sized Eulerian tile.  We
 // therefore bin the particles by the Eulerian tile of their home cell every force evaluation (counting
-// sort: one returning int atomic per particle, one scan, one reorder pass), and then
+// sort: block-aggregated atomics, one scan, one reorder pass), and then
 //   * scatter: one workgroup per (tile, chunk of <= `chunk` particles) accumulates W into an LDS copy of the
-//     tile plus a halo of `R` cells with LDS fp64 atomics and flushes its non-zero cells to HBM once
+//     tile plus a halo of `R` cells with LDS float atomics and flushes its non-zero cells to HBM once
 //     (a few coalesced global atomics per cell instead of ~34 scattered ones per particle);
 //   * gather: the same work items stage part_like (tile + halo) in LDS and each particle reads its 81
 //     stencil cells from there.
-// Arithmetic per (particle, cell) pair is identical to the direct kernels above, which stay as the fallback.
+// The (particle, cell) pair set is identical to the direct kernels above, which stay as the fallback; the
+// spline evaluations use fast_rsqrt (<= 2 ulp) instead of IEEE sqrt + divide.
 // ======================================================================================================
 struct TilePar {
   int tx, ty, tz;     // tile shape in cells (z fastest)
   int ntx, nty, ntz;  // tiles per axis
   int ntiles;
-  int R;              // halo = stencil reach
+  int R;              // halo = farthest stencil offset
   int lx, ly, lz;     // LDS tile shape = t + 2R
   int chunk;          // max particles per work item
 };
@@ -821,6 +862,12 @@ constexpr int kSortFlagNoScatter = 1 << 30;  // record flag: particle fails getD
 __device__ __forceinline__ int tile_of(const TilePar &tp, int n, long long ix, long long iy, long long iz) {
   const int cx = (int)(ix % n), cy = (int)(iy % n), cz = (int)(iz % n);
   return (cz / tp.tz) + tp.ntz * ((cy / tp.ty) + tp.nty * (cx / tp.tx));
+}
+
+// Home cell of a position: (ULONG)(xp/d1), massFunctions.cc:434-436 (same expression in every kernel).
+template <typename T>
+__device__ __forceinline__ long long home_cell(T x, T d) {
+  return (long long)(x / d);
 }
 
 // Workgroup -> particles.  When 16 divides n a workgroup takes a 4 x 4 x 16 brick of the Lagrangian lattice
@@ -848,9 +895,10 @@ __device__ __forceinline__ long long brick_particle(const Geo &g, int &i, int &j
 // an LDS hash table, then reserves one contiguous rank range per distinct tile with a single global atomic
 // (a handful per workgroup instead of one returning atomic per particle on ~n^3/2048 hot counters).
 // Particles with a non-finite position are left out (tile -1); the gather gives them V = 0.
+template <typename T>
 __global__ void __launch_bounds__(256)
-k_bin(Geo g, PosPar pp, SphPar sp, TilePar tp, const double *__restrict__ psi, int *__restrict__ cnt,
-      int2 *__restrict__ tile_rank, double *__restrict__ V) {
+k_bin(Geo g, PosPar pp, SphPar sp, TilePar tp, const T *__restrict__ psi, int *__restrict__ cnt,
+      int2 *__restrict__ tile_rank, T *__restrict__ V) {
   constexpr int kSlots = 512;
   __shared__ int hkey[kSlots], hcnt[kSlots], hbase[kSlots];
   for (int s = threadIdx.x; s < kSlots; s += blockDim.x) {
@@ -863,13 +911,12 @@ k_bin(Geo g, PosPar pp, SphPar sp, TilePar tp, const double *__restrict__ psi, i
   const bool live = p < g.N;
   int t = -1, slot = 0, local = 0, flag = 0;
   if (live) {
-    double x, y, z;
-    particle_pos(pp, i, j, k, psi[p], psi[p + g.N], psi[p + 2 * g.N], x, y, z);
-    if (x >= 0. && x <= g.L && y >= 0. && y <= g.L && z >= 0. && z <= g.L) {
-      t = tile_of(tp, g.n, (long long)(x / g.d), (long long)(y / g.d), (long long)(z / g.d));
-      const bool in_domain = (x >= sp.min1 && x < sp.min1 + g.L) && (y >= sp.min2 && y < sp.min2 + g.L) &&
-                             (z >= sp.min3 && z < sp.min3 + g.L);  // massFunctions.cc:426
-      flag = in_domain ? 0 : kSortFlagNoScatter;
+    T x, y, z;
+    particle_pos<T>(pp, i, j, k, psi[p], psi[p + g.N], psi[p + 2 * g.N], x, y, z);
+    if (pos_ok(g, x, y, z)) {
+      const T d = (T)g.d;
+      t = tile_of(tp, g.n, home_cell(x, d), home_cell(y, d), home_cell(z, d));
+      flag = in_domain(g, sp, x, y, z) ? 0 : kSortFlagNoScatter;
       slot = (int)(((unsigned)t * 2654435761u) >> 23) & (kSlots - 1);
       for (;;) {
         const int old = atomicCAS(&hkey[slot], 0, t + 1);
@@ -878,9 +925,9 @@ k_bin(Geo g, PosPar pp, SphPar sp, TilePar tp, const double *__restrict__ psi, i
       }
       local = atomicAdd(&hcnt[slot], 1);
     } else {
-      V[p] = 0.;
-      V[p + g.N] = 0.;
-      V[p + 2 * g.N] = 0.;
+      V[p] = T(0);
+      V[p + g.N] = T(0);
+      V[p + 2 * g.N] = T(0);
     }
   }
   __syncthreads();
@@ -933,17 +980,18 @@ k_scan_tiles(TilePar tp, const int *__restrict__ cnt, int *__restrict__ off, int
 }
 
 // Pass 3: write each particle's record (position, original index | flag) to its sorted slot.
+template <typename T>
 __global__ void __launch_bounds__(256)
-k_reorder(Geo g, PosPar pp, const double *__restrict__ psi, const int2 *__restrict__ tile_rank,
-          const int *__restrict__ off, double *__restrict__ sx, double *__restrict__ sy, double *__restrict__ sz,
+k_reorder(Geo g, PosPar pp, const T *__restrict__ psi, const int2 *__restrict__ tile_rank,
+          const int *__restrict__ off, T *__restrict__ sx, T *__restrict__ sy, T *__restrict__ sz,
           int *__restrict__ sidx) {
   int i, j, k;
   const long long p = brick_particle(g, i, j, k);
   if (p >= g.N) return;
   const int2 tr = tile_rank[p];
   if (tr.x < 0) return;
-  double x, y, z;
-  particle_pos(pp, i, j, k, psi[p], psi[p + g.N], psi[p + 2 * g.N], x, y, z);
+  T x, y, z;
+  particle_pos<T>(pp, i, j, k, psi[p], psi[p + g.N], psi[p + 2 * g.N], x, y, z);
   const int slot = off[tr.x] + (tr.y & ~kSortFlagNoScatter);
   sx[slot] = x;
   sy[slot] = y;
@@ -980,17 +1028,19 @@ __device__ __forceinline__ bool tile_work(const TilePar &tp, const int *__restri
 }
 
 // getDensity_SPH on sorted particles: LDS accumulation per (tile, chunk), one flush.
+template <typename T>
 __global__ void __launch_bounds__(256)
-k_scatter_tile(Geo g, SphPar sp, TilePar tp, const int4 *__restrict__ cols, int ncol, int reorder, double *sx,
-               double *sy, double *sz, int *sidx, const int *__restrict__ off, const int *__restrict__ woff,
-               double *__restrict__ rho) {
-  extern __shared__ double s_tile_acc[];
+k_scatter_tile(Geo g, SphPar sp, TilePar tp, const int4 *__restrict__ cols, int ncol, int reorder, T *sx, T *sy, T *sz,
+               int *sidx, const int *__restrict__ off, const int *__restrict__ woff, T *__restrict__ rho) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw_scatter[];
+  double *s_tile_acc = reinterpret_cast<double *>(s_raw_scatter);  // accumulate in double also for float fields
   int tile, pb, pe;
   if (!tile_work(tp, off, woff, tile, pb, pe)) return;
   const int ncell = tp.lx * tp.ly * tp.lz;
-  int4 *s_cols = reinterpret_cast<int4 *>(s_tile_acc + ((ncell + 1) & ~1));
+  int4 *s_cols = reinterpret_cast<int4 *>(s_raw_scatter + (((size_t)ncell * sizeof(double) + 15) & ~(size_t)15));
   for (int m = threadIdx.x; m < ncol; m += blockDim.x) s_cols[m] = cols[m];
   for (int c = threadIdx.x; c < ncell; c += blockDim.x) s_tile_acc[c] = 0.;
+  const T d = (T)g.d;
   // Prologue: order this work item's records by the octant of the particle's sub-cell offset (in place, for
   // the gather kernel too).  The 64 lanes of a wave then share the set of stencil cells that can pass the
   // `r/h <= 2` test (51 instead of 81 on average), and a wave pays for every candidate ANY of its lanes needs.
@@ -1000,7 +1050,7 @@ k_scatter_tile(Geo g, SphPar sp, TilePar tp, const int4 *__restrict__ cols, int 
     __shared__ int hist[8], base[8];
     if (threadIdx.x < 8) hist[threadIdx.x] = 0;
     __syncthreads();
-    double rx[kPer], ry[kPer], rz[kPer];
+    T rx[kPer], ry[kPer], rz[kPer];
     int id[kPer], key[kPer], rank[kPer];
 #pragma unroll
     for (int m = 0; m < kPer; m++) {
@@ -1010,8 +1060,9 @@ k_scatter_tile(Geo g, SphPar sp, TilePar tp, const int4 *__restrict__ cols, int 
         ry[m] = sy[s];
         rz[m] = sz[s];
         id[m] = sidx[s];
-        const double fx = rx[m] / g.d, fy = ry[m] / g.d, fz = rz[m] / g.d;
-        key[m] = (((fx - floor(fx)) >= 0.5) << 2) | (((fy - floor(fy)) >= 0.5) << 1) | ((fz - floor(fz)) >= 0.5);
+        const T fx = rx[m] / d, fy = ry[m] / d, fz = rz[m] / d;
+        key[m] = (((fx - r_floor(fx)) >= T(0.5)) << 2) | (((fy - r_floor(fy)) >= T(0.5)) << 1) |
+                 ((fz - r_floor(fz)) >= T(0.5));
         rank[m] = atomicAdd(&hist[key[m]], 1);
       }
     }
@@ -1041,12 +1092,12 @@ k_scatter_tile(Geo g, SphPar sp, TilePar tp, const int4 *__restrict__ cols, int 
   const int tzi = tile % tp.ntz, tyi = (tile / tp.ntz) % tp.nty, txi = tile / (tp.ntz * tp.nty);
   const int ox = txi * tp.tx - tp.R, oy = tyi * tp.ty - tp.R, oz = tzi * tp.tz - tp.R;  // global cell of LDS (0,0,0)
   const int n = g.n, R = sp.reach;
-  const double d = g.d;
+  const T r2_lim = (T)sp.r2_lim, h_inv = (T)sp.h_inv, w_norm = (T)sp.w_norm;
   for (int s = pb + threadIdx.x; s < pe; s += blockDim.x) {
     if (sidx[s] & kSortFlagNoScatter) continue;
-    const double x = sx[s], y = sy[s], z = sz[s];
-    const long long ix = (long long)(x / d), iy = (long long)(y / d), iz = (long long)(z / d);
-    const double ccx = ((double)ix + 0.5) * d, ccy = ((double)iy + 0.5) * d, ccz = ((double)iz + 0.5) * d;
+    const T x = sx[s], y = sy[s], z = sz[s];
+    const long long ix = home_cell(x, d), iy = home_cell(y, d), iz = home_cell(z, d);
+    const T ccx = ((T)ix + T(0.5)) * d, ccy = ((T)iy + T(0.5)) * d, ccz = ((T)iz + T(0.5)) * d;
     const int hx = (int)(ix % n) - ox, hy = (int)(iy % n) - oy, hz = (int)(iz % n) - oz;  // home cell in LDS coords
     if ((unsigned)(hx - tp.R) >= (unsigned)tp.tx || (unsigned)(hy - tp.R) >= (unsigned)tp.ty ||
         (unsigned)(hz - tp.R) >= (unsigned)tp.tz)
@@ -1055,36 +1106,36 @@ k_scatter_tile(Geo g, SphPar sp, TilePar tp, const int4 *__restrict__ cols, int 
       // Exact hull (host-verified: no cell outside it can satisfy r/h <= 2): 81 candidates instead of 343.
       for (int m = 0; m < ncol; ++m) {
         const int4 c = s_cols[m];
-        const double dx = x - (ccx + (double)c.x * d);
-        const double dy = y - (ccy + (double)c.y * d);
-        const double r2ab = dx * dx + dy * dy;
-        if (r2ab > sp.r2_lim) continue;
+        const T dx = x - (ccx + (T)c.x * d);
+        const T dy = y - (ccy + (T)c.y * d);
+        const T r2ab = dx * dx + dy * dy;
+        if (r2ab > r2_lim) continue;
         double *row = s_tile_acc + tp.lz * ((hy + c.y) + tp.ly * (hx + c.x)) + hz;
         for (int i3 = c.z; i3 <= c.w; ++i3) {
-          const double dz = z - (ccz + (double)i3 * d);
-          const double r2 = r2ab + dz * dz;
-          if (r2 <= sp.r2_lim) {
-            const double q = (r2 * fast_rsqrt(fmax(r2, 1e-280))) * sp.h_inv;
-            if (q <= 2.) atomic_add_f64(row + i3, sph_w_sel(q, sp.w_norm));
+          const T dz = z - (ccz + (T)i3 * d);
+          const T r2 = r2ab + dz * dz;
+          if (r2 <= r2_lim) {
+            const T q = (r2 * fast_rsqrt(r_max(r2, tiny_pos<T>()))) * h_inv;
+            if (q <= T(2)) atomic_add_r(row + i3, (double)sph_w_sel<T>(q, w_norm));
           }
         }
       }
     } else {
       for (int i1 = -R; i1 <= R; ++i1) {
-        const double dx = x - (ccx + (double)i1 * d);
-        const double dx2 = dx * dx;
-        if (dx2 > sp.r2_lim) continue;
+        const T dx = x - (ccx + (T)i1 * d);
+        const T dx2 = dx * dx;
+        if (dx2 > r2_lim) continue;
         for (int i2 = -R; i2 <= R; ++i2) {
-          const double dy = y - (ccy + (double)i2 * d);
-          const double r2ab = dx2 + dy * dy;
-          if (r2ab > sp.r2_lim) continue;
+          const T dy = y - (ccy + (T)i2 * d);
+          const T r2ab = dx2 + dy * dy;
+          if (r2ab > r2_lim) continue;
           double *row = s_tile_acc + tp.lz * ((hy + i2) + tp.ly * (hx + i1)) + hz;
           for (int i3 = -R; i3 <= R; ++i3) {
-            const double dz = z - (ccz + (double)i3 * d);
-            const double r2 = r2ab + dz * dz;
-            if (r2 > sp.r2_lim) continue;
-            const double q = (r2 * fast_rsqrt(fmax(r2, 1e-280))) * sp.h_inv;
-            if (q <= 2.) atomic_add_f64(row + i3, sph_w_sel(q, sp.w_norm));
+            const T dz = z - (ccz + (T)i3 * d);
+            const T r2 = r2ab + dz * dz;
+            if (r2 > r2_lim) continue;
+            const T q = (r2 * fast_rsqrt(r_max(r2, tiny_pos<T>()))) * h_inv;
+            if (q <= T(2)) atomic_add_r(row + i3, (double)sph_w_sel<T>(q, w_norm));
           }
         }
       }
@@ -1096,21 +1147,23 @@ k_scatter_tile(Geo g, SphPar sp, TilePar tp, const int4 *__restrict__ cols, int 
     if (v != 0.) {
       const int cz = c % tp.lz, cy = (c / tp.lz) % tp.ly, cx = c / (tp.lz * tp.ly);
       const int gx = (ox + cx + n) % n, gy = (oy + cy + n) % n, gz = (oz + cz + n) % n;
-      atomic_add_f64(rho + gz + (long long)n * (gy + (long long)n * gx), v);
+      atomic_add_r(rho + gz + (long long)n * (gy + (long long)n * gx), (T)v);
     }
   }
 }
 
 // likelihood_calc_V_SPH on sorted particles: part_like tile + halo staged in LDS.
+template <typename T>
 __global__ void __launch_bounds__(256)
-k_gather_tile(Geo g, HullPar hp, TilePar tp, int rsd, const double *__restrict__ sx, const double *__restrict__ sy,
-              const double *__restrict__ sz, const int *__restrict__ sidx, const int *__restrict__ off,
-              const int *__restrict__ woff, const double *__restrict__ plike, double *__restrict__ V) {
-  extern __shared__ double s_tile_pl[];
+k_gather_tile(Geo g, HullPar hp, TilePar tp, int rsd, const T *__restrict__ sx, const T *__restrict__ sy,
+              const T *__restrict__ sz, const int *__restrict__ sidx, const int *__restrict__ off,
+              const int *__restrict__ woff, const T *__restrict__ plike, T *__restrict__ V) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw_gather[];
+  T *s_tile_pl = reinterpret_cast<T *>(s_raw_gather);
   int tile, pb, pe;
   if (!tile_work(tp, off, woff, tile, pb, pe)) return;
   const int ncell = tp.lx * tp.ly * tp.lz;
-  int4 *s_cols = reinterpret_cast<int4 *>(s_tile_pl + ((ncell + 1) & ~1));
+  int4 *s_cols = reinterpret_cast<int4 *>(s_raw_gather + (((size_t)ncell * sizeof(T) + 15) & ~(size_t)15));
   for (int m = threadIdx.x; m < hp.ncol; m += blockDim.x) s_cols[m] = hp.cols[m];
   const int n = g.n;
   const int tzi = tile % tp.ntz, tyi = (tile / tp.ntz) % tp.nty, txi = tile / (tp.ntz * tp.nty);
@@ -1121,29 +1174,29 @@ k_gather_tile(Geo g, HullPar hp, TilePar tp, int rsd, const double *__restrict__
     s_tile_pl[c] = plike[gz + (long long)n * (gy + (long long)n * gx)];
   }
   __syncthreads();
-  const double d_h = hp.d_h;
+  const T d = (T)g.d, d_h = (T)hp.d_h, h_inv = (T)hp.h_inv, norm = (T)hp.norm;
   for (int s = pb + threadIdx.x; s < pe; s += blockDim.x) {
-    const double px = sx[s], py = sy[s], pz = sz[s];
-    const int ix = (int)(px / g.d), iy = (int)(py / g.d), iz = (int)(pz / g.d);
-    const double dpcx = px * hp.h_inv - ((double)ix + 0.5) * d_h;
-    const double dpcy = py * hp.h_inv - ((double)iy + 0.5) * d_h;
-    const double dpcz = pz * hp.h_inv - ((double)iz + 0.5) * d_h;
+    const T px = sx[s], py = sy[s], pz = sz[s];
+    const int ix = (int)home_cell(px, d), iy = (int)home_cell(py, d), iz = (int)home_cell(pz, d);
+    const T dpcx = px * h_inv - ((T)ix + T(0.5)) * d_h;
+    const T dpcy = py * h_inv - ((T)iy + T(0.5)) * d_h;
+    const T dpcz = pz * h_inv - ((T)iz + T(0.5)) * d_h;
     const int hx = (ix % n) - ox, hy = (iy % n) - oy, hz = (iz % n) - oz;
-    double vx = 0., vy = 0., vz = 0.;
+    T vx = T(0), vy = T(0), vz = T(0);
     const bool home_ok = (unsigned)(hx - tp.R) < (unsigned)tp.tx && (unsigned)(hy - tp.R) < (unsigned)tp.ty &&
                          (unsigned)(hz - tp.R) < (unsigned)tp.tz;  // always true; keeps LDS indexing safe
     for (int m = 0; home_ok && m < hp.ncol; ++m) {
       const int4 c = s_cols[m];
-      const double xh = dpcx - (double)c.x * d_h;
-      const double yh = dpcy - (double)c.y * d_h;
-      const double r2ab = xh * xh + yh * yh;
-      if (r2ab > 4.) continue;
-      const double *row = s_tile_pl + tp.lz * ((hy + c.y) + tp.ly * (hx + c.x)) + hz;
-      double zh = dpcz - (double)c.z * d_h;
+      const T xh = dpcx - (T)c.x * d_h;
+      const T yh = dpcy - (T)c.y * d_h;
+      const T r2ab = xh * xh + yh * yh;
+      if (r2ab > T(4)) continue;
+      const T *row = s_tile_pl + tp.lz * ((hy + c.y) + tp.ly * (hx + c.x)) + hz;
+      T zh = dpcz - (T)c.z * d_h;
       for (int i3 = c.z; i3 <= c.w; ++i3) {
-        const double q_sq = r2ab + zh * zh;
-        if (q_sq <= 4.) {
-          const double common = row[i3] * sph_grad_partial(q_sq, hp.norm);
+        const T q_sq = r2ab + zh * zh;
+        if (q_sq <= T(4)) {
+          const T common = row[i3] * sph_grad_partial<T>(q_sq, norm);
           vx += common * xh;
           vy += common * yh;
           vz += common * zh;
@@ -1151,10 +1204,11 @@ k_gather_tile(Geo g, HullPar hp, TilePar tp, int rsd, const double *__restrict__
         zh -= d_h;
       }
     }
-    vx *= hp.normalize;
-    vy *= hp.normalize;
-    vz *= hp.normalize;
-    if (rsd) vz += hp.f1 * vz;
+    const T normalize = (T)hp.normalize;
+    vx *= normalize;
+    vy *= normalize;
+    vz *= normalize;
+    if (rsd) vz += (T)hp.f1 * vz;
     const long long p = sidx[s] & ~kSortFlagNoScatter;
     V[p] = vx;
     V[p + g.N] = vy;

@@ -98,7 +98,7 @@ def load():
     return lib
 
 
-def make_config(params, device=0):
+def make_config(params, device=0, precision=0):
     cfg = BchmcConfig()
     cfg.abi_version = ABI_VERSION
     cfg.Nx = int(params.Nx)
@@ -107,7 +107,7 @@ def make_config(params, device=0):
         if name in ("abi_version", "Nx", "L", "precision", "device"):
             continue
         setattr(cfg, name, getattr(params, name))
-    cfg.precision = 0
+    cfg.precision = int(precision)
     cfg.device = int(device)
     return cfg
 
@@ -120,13 +120,16 @@ def _p(a):
 class Engine:
     """One chain on one GPU: owns a ``bchmc_handle``."""
 
-    def __init__(self, params, device=0):
+    def __init__(self, params, device=0, precision=0):
+        """precision 0: fp64 field arrays (reference DOUBLE_PREC); 1: fp32 field arrays (BASELINE config 5).
+        Host arrays are float64 either way."""
         self.lib = load()
+        self.precision = int(precision)
         self.params = params
         self.Nx = int(params.Nx)
         self.N = self.Nx ** 3
         self.h = C.c_void_p()
-        cfg = make_config(params, device)
+        cfg = make_config(params, device, precision)
         rc = self.lib.bchmc_create(C.byref(cfg), C.byref(self.h))
         if rc:
             detail = self.lib.bchmc_last_error(self.h).decode() if self.h else ""

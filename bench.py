@@ -35,6 +35,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-nx", type=int, default=0, help="grid of the CPU-baseline sample (default: same as --nx)")
     ap.add_argument("--no-kernel-profile", action="store_true")
+    ap.add_argument("--fp32", action="store_true", help="fp32 field arrays (BASELINE config 5); tolerance re-stated")
     ap.add_argument("--backend", default="nccl", help="process-group backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal only: every rank uses cuda:0 (never for reported numbers)")
@@ -118,7 +119,7 @@ def main():
     ring = EpsRing()
 
     f = inputs.make_fields(params)
-    engine = Engine(params, device=local_rank)
+    engine = Engine(params, device=local_rank, precision=1 if args.fp32 else 0)
     engine.upload(signal_PS=f["signal_PS"], mass_f=f["mass_f"])
     # mock data: forward model of the truth field on the GPU, then the reference's noise model
     if params.likelihood != 3:
@@ -187,7 +188,8 @@ def main():
         N = params.N
         steps_total = args.steps * world
         value = steps_total / wall
-        achieved = ALGO_BYTES_PER_CELL_STEP * N * args.steps / (gpu_ms * 1e-3) / 1e9  # per GPU, device time
+        algo = ALGO_BYTES_PER_CELL_STEP // (2 if args.fp32 else 1)  # 272 N bytes per step with fp32 fields
+        achieved = algo * N * args.steps / (gpu_ms * 1e-3) / 1e9  # per GPU, device time
         traffic, traffic_src = pmc_traffic(params.Nx) if (rsd and params.likelihood == 1) else (None, None)
         out = {
             "metric": "HMC leapfrog steps/sec on %d^3 grid" % params.Nx,
@@ -200,13 +202,15 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f64",
+            "dtype": "f32" if args.fp32 else "f64",
             "data": "synthetic",
             "config": {
                 "workload": "%d^3 grid, L=200 Mpc/h, Gaussian prior, Zel'dovich%s (reference behaviour of '2LPT+RSD', "
-                            "SURVEY M3), likelihood=%d, SPH mass kernel (mk=3), calc_h=2, mass_type=1, fp64; one "
+                            "SURVEY M3), likelihood=%d, SPH mass kernel (mk=3), calc_h=2, mass_type=1, %s; one "
                             "trajectory of %d leapfrog steps per chain" % (params.Nx, " + plane-parallel RSD" if rsd else "",
-                                                                           params.likelihood, args.steps),
+                                                                           params.likelihood,
+                                                                           "fp32 field arrays" if args.fp32 else "fp64",
+                                                                           args.steps),
                 "grid": params.Nx, "chains": world, "parallelism": "independent chains, 1 per GPU",
                 "rehearsal_single_device": bool(args.single_device),
                 "eps": eps, "steps_done": int(done), "finite": finite,
@@ -220,7 +224,7 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": traffic,
                 "traffic_source": traffic_src,
-                "algorithmic_bytes_per_step": ALGO_BYTES_PER_CELL_STEP * N,
+                "algorithmic_bytes_per_step": algo * N,
                 "device_ms_per_step": round(gpu_ms / args.steps, 4),
                 "kernels": kernels,
             },

@@ -44,7 +44,9 @@ typedef struct bchmc_config {
   double grad_psi_prior_factor, grad_psi_likeli_factor, deltaQ_factor;
   double rho_c, delta_min, biasP, biasE;
   double ascale, D1, D2, OM, OL;
-  int32_t precision;         /* 0: fp64 fields (reference DOUBLE_PREC).  1 (fp32 fields): not yet built */
+  int32_t precision;         /* 0: fp64 field arrays (reference DOUBLE_PREC); 1: fp32 field arrays (SINGLE_PREC-like:
+                              * storage + particle-mesh arithmetic in float, k-space arithmetic and reductions in
+                              * double).  The ABI's arrays are double in both modes. */
   int32_t device;            /* HIP device ordinal */
 } bchmc_config;
 

@@ -181,3 +181,32 @@ def test_error_conventions():
         c2.p.planepar = 0
         c2.engine().gradient(c2.q0)
     assert ei.value.code == 3
+
+
+# ---- fp32 field arrays (BASELINE config 5): storage and particle-mesh arithmetic in float, k-space arithmetic and
+# reductions in double.  Re-stated tolerances: rel-L2 <= 1e-4 on q1, p1; energies rel <= 1e-5.
+TOL_F32_FIELD = 2e-5
+TOL_F32_TRAJ = 1e-4
+TOL_F32_ENERGY = 1e-5
+
+
+@pytest.mark.parametrize("kw", [dict(likelihood=1, rsd_model=1, sfmodel=2), dict(likelihood=1, rsd_model=0),
+                                dict(likelihood=3), dict(likelihood=1, mass_type=5)],
+                         ids=["gauss_rsd", "gauss", "grf", "mass5"])
+def test_fp32_field_mode(kw):
+    c = Case(Nx=16, **kw)
+    e = c.engine(precision=1)
+    g, gp, gl = c.oracle.gradient_psi(c.q0)
+    gg = e.gradient(c.q0)
+    assert rel_l2(e.fetch("grad_prior"), gp) < TOL_F32_FIELD
+    assert rel_l2(gg, g) < 10 * TOL_F32_FIELD
+    if c.p.likelihood != 3:
+        assert rel_l2(e.fetch("deltaX"), c.oracle.get("deltaX")) < 10 * TOL_F32_FIELD
+    q1o, p1o, _ = c.oracle.Hamiltonian_EoM(c.q0, c.p0, c.eps, 10)
+    q1, p1, done = e.leapfrog(c.q0, c.p0, c.eps, 10)
+    assert done == 10
+    assert rel_l2(q1, q1o) < TOL_F32_TRAJ and rel_l2(p1, p1o) < TOL_F32_TRAJ
+    dHo, to = c.oracle.delta_Hamiltonian(c.q0, c.p0, q1o, p1o)
+    dH, t = e.delta_hamiltonian(c.q0, c.p0, q1o, p1o)
+    assert np.all(np.abs(t - to) <= TOL_F32_ENERGY * np.abs(to))
+    e.close()

@@ -58,8 +58,8 @@ class Case:
         return dict(signal_PS=self.signal_PS, mass_f=self.mass_f, mass_r=self.mass_r, window=self.window,
                     noise=self.noise, nobs=self.nobs)
 
-    def engine(self, device=0):
+    def engine(self, device=0, precision=0):
         from barcode_amd.engine import Engine
-        e = Engine(self.p, device=device)
+        e = Engine(self.p, device=device, precision=precision)
         e.upload(**self.arrays())
         return e
