@@ -210,3 +210,79 @@ def test_fp32_field_mode(kw):
     dH, t = e.delta_hamiltonian(c.q0, c.p0, q1o, p1o)
     assert np.all(np.abs(t - to) <= TOL_F32_ENERGY * np.abs(to))
     e.close()
+
+
+# ---- code paths that the default 16^3 cases do not reach ----------------------------------------------------
+@pytest.mark.parametrize("nx,kw", [
+    (10, dict(likelihood=1, rsd_model=1)),                       # no tile shape divides 10: direct (unsorted) kernels
+    (12, dict(likelihood=1, rsd_model=0)),                       # 4 x 4 x 4 tiles
+    (24, dict(likelihood=0, rsd_model=0)),                       # 8 x 8 x 8 tiles
+    (16, dict(likelihood=1, rsd_model=1, particle_kernel_h_rel=1.3)),   # hull not exact: cube loop, halo = reach
+    (16, dict(likelihood=1, rsd_model=0, particle_kernel_h_rel=0.8)),   # smaller kernel
+    (16, dict(likelihood=1, rsd_model=0, min1=1.0, min2=2.0, min3=0.5)),  # xllc != 0: particles below min are dropped
+], ids=["n10_direct", "n12_tile4", "n24_tile8", "h1.3", "h0.8", "xllc"])
+def test_other_tilings_and_kernel_sizes(nx, kw):
+    import warnings
+    c = Case(Nx=nx, **kw)
+    e = c.engine()
+    g, gp, gl = c.oracle.gradient_psi(c.q0)
+    gg = e.gradient(c.q0)
+    assert rel_l2(e.fetch("rho"), c.oracle.getDensity(3, *[c.oracle.get(k) for k in ("posx", "posy", "posz")])) < TOL_FIELD
+    assert rel_l2(gg, g) < 10 * TOL_FIELD
+    q1o, p1o, _ = c.oracle.Hamiltonian_EoM(c.q0, c.p0, c.eps, 5)
+    q1, p1, done = e.leapfrog(c.q0, c.p0, c.eps, 5)
+    assert done == 5
+    assert rel_l2(q1, q1o) < TOL_TRAJ_10 and rel_l2(p1, p1o) < TOL_TRAJ_10
+    e.close()
+
+
+def test_direct_kernels_when_tiling_is_disabled(monkeypatch):
+    """BCHMC_NO_TILES=1 forces the unsorted scatter/gather kernels (IEEE sqrt/divide, global atomics)."""
+    monkeypatch.setenv("BCHMC_NO_TILES", "1")
+    c = Case(Nx=16, likelihood=1, rsd_model=1)
+    e = c.engine()
+    g, _, _ = c.oracle.gradient_psi(c.q0)
+    assert rel_l2(e.gradient(c.q0), g) < 10 * TOL_FIELD
+    q1o, p1o, _ = c.oracle.Hamiltonian_EoM(c.q0, c.p0, c.eps, 5)
+    q1, p1, _ = e.leapfrog(c.q0, c.p0, c.eps, 5)
+    assert rel_l2(q1, q1o) < TOL_TRAJ_10 and rel_l2(p1, p1o) < TOL_TRAJ_10
+    e.close()
+
+
+def test_device_resident_entry_points():
+    """bchmc_leapfrog_device / bchmc_energies_device on torch tensors give the host-array results."""
+    import torch
+    c = Case(Nx=16, likelihood=1, rsd_model=1)
+    e = c.engine()
+    dev = torch.device("cuda", 0)
+    q0 = torch.from_numpy(c.q0.reshape(-1).copy()).to(dev)
+    p0 = torch.from_numpy(c.p0.reshape(-1).copy()).to(dev)
+    q1, p1 = torch.empty_like(q0), torch.empty_like(p0)
+    e.leapfrog_device(q0, p0, q1, p1, c.eps, 6)
+    assert e.steps_done() == 6
+    qh, ph, _ = e.leapfrog(c.q0, c.p0, c.eps, 6)
+    assert rel_l2(q1.cpu().numpy(), qh) < 1e-12 and rel_l2(p1.cpu().numpy(), ph) < 1e-12
+    assert torch.equal(q0.cpu(), torch.from_numpy(c.q0.reshape(-1)))  # inputs untouched
+    en_d = e.energies_device(q1, p1)
+    en_h = e.energies(qh, ph)
+    assert np.allclose(en_d, en_h, rtol=1e-11)
+    e.close()
+
+
+def test_host_side_mirror_of_the_reference_interface():
+    """barcode_amd.hamil: Hamiltonian_EoM draws (Neps, epsilon) exactly as HMC.cc:260-264 and keeps the log scalars."""
+    from barcode_amd import hamil
+    c = Case(Nx=16, likelihood=1)
+    hd = hamil.HamilData(c.p, N_eps_fac=8.0, eps_fac=c.eps * 2, **c.arrays())
+    draws = iter([0.55, 0.5])  # -> Neps = int(8 * 0.55) + 1 = 5, epsilon = eps_fac * 0.5
+    qf, pf = hamil.Hamiltonian_EoM(hd, c.q0, c.p0, lambda: next(draws))
+    assert hd.numerical.Neps == 5 and np.isclose(hd.numerical.epsilon, c.eps) and hd.numerical.count_attempts == 1
+    q1o, p1o, _ = c.oracle.Hamiltonian_EoM(c.q0, c.p0, c.eps, 5)
+    assert rel_l2(qf, q1o) < TOL_TRAJ_10 and rel_l2(pf, p1o) < TOL_TRAJ_10
+    dH = hamil.delta_Hamiltonian(hd, c.q0, c.p0, qf, pf)
+    dHo, to = c.oracle.delta_Hamiltonian(c.q0, c.p0, q1o, p1o)
+    n = hd.numerical
+    assert np.allclose([n.H_kin_i, n.psi_prior_i, n.psi_likeli_i, n.H_kin_f, n.psi_prior_f, n.psi_likeli_f], to, rtol=1e-9)
+    assert abs(dH - dHo) <= 1e-8 * abs(to).max()
+    assert rel_l2(hamil.gradient_psi(hd, c.q0), c.oracle.gradient_psi(c.q0)[0]) < 10 * TOL_FIELD
+    hd.engine.close()
