@@ -69,6 +69,10 @@ struct bchmc_handle {
   void *conv = nullptr;                              // 3 N, lazily allocated for calc_h 0 / 3
   double *convF = nullptr;                           // Nh: SPH kernel transform table for calc_h = 3
   double *dstage = nullptr;                          // 2 N doubles: ABI <-> T conversion staging
+  // device-resident chain: current sample and momenta in k-space, energy partials
+  void *cq = nullptr, *cp = nullptr;                 // Nh complex each
+  double *part6 = nullptr;                           // 6 * kRedBlocks doubles
+  bool have_cq = false, have_cp = false, have_prop = false;
   double *rho_part = nullptr, *partA = nullptr;      // kRedBlocks doubles each
   double *guard = nullptr;                           // guard slots, one per step
   size_t guard_cap = 0;
@@ -609,10 +613,22 @@ struct Pipe {
     return fft_exec(h, h->r2c1, h->iop, h->tC, BCHMC_K_FFT_R2C);
   }
 
-  static int leapfrog_core(bchmc_handle *h, const double *d_q0, const double *d_p0, double *d_q1, double *d_p1,
-                           double eps, uint64_t neps) {
-    CHK(check_inputs(h));
-    if (eps > 2.) eps = 2.;  // HMC.cc:263-264
+  // Optional taps for the resident-chain path: -log L partials of the forward model at the first and the last
+  // force evaluation of a trajectory (the same forward models delta_Hamiltonian would recompute, HMC.cc:214-225).
+  struct Tap {
+    double *like_i, *like_f;
+  };
+
+  static int tap_loglike(bchmc_handle *h, double *partials) {
+    k_loglike<T><<<kRedBlocks, 256, 0, h->stream>>>(h->g, make_like(h), R(h->rho), h->rho_part,
+                                                    R(h->in_arr[BCHMC_F_NOBS]), R(h->in_arr[BCHMC_F_NOISE]),
+                                                    R(h->in_arr[BCHMC_F_WINDOW]), partials);
+    HIPCHK(hipGetLastError());
+    return BCHMC_OK;
+  }
+
+  // Hamiltonian_EoM (HMC.cc:275-365) on the k-space state already in (qk, pk).
+  static int trajectory(bchmc_handle *h, double eps, uint64_t neps, const Tap *tap) {
     if (neps + 1 > h->guard_cap) {
       if (h->guard) (void)hipFree(h->guard);
       h->guard = nullptr;
@@ -623,14 +639,12 @@ struct Pipe {
     k_init_ctl<<<1, 1, 0, h->stream>>>(h->stop, h->steps_done, (unsigned long long)neps);
     HIPCHK(hipGetLastError());
 
-    CHK(r2c_state(h, d_q0, h->ioq, h->qk));
-    CHK(r2c_state(h, d_p0, h->iop, h->pk));
-
     const double a = h->c.grad_psi_prior_factor;
     int like_mode = 2;
     double b = 0.;
     // 0) gradient at t = 0 (HMC.cc:279-280)
     CHK(force_sources(h, false, &like_mode, &b));
+    if (tap && tap->like_i) CHK(tap_loglike(h, tap->like_i));
     CHK(launch_assemble<false>(h, a, b, like_mode, 0., nullptr));
 
     const bool fused_za = (h->c.likelihood != 3);
@@ -659,10 +673,121 @@ struct Pipe {
         HIPCHK(hipGetLastError());
       }
       CHK(force_sources(h, fused_za, &like_mode, &b));
+      if (tap && tap->like_f && s + 1 == neps) CHK(tap_loglike(h, tap->like_f));
       CHK(launch_assemble<true>(h, a, b, like_mode, 0.5 * eps, h->guard + s));
     }
+    return BCHMC_OK;
+  }
+
+  static int leapfrog_core(bchmc_handle *h, const double *d_q0, const double *d_p0, double *d_q1, double *d_p1,
+                           double eps, uint64_t neps) {
+    CHK(check_inputs(h));
+    if (eps > 2.) eps = 2.;  // HMC.cc:263-264
+    CHK(r2c_state(h, d_q0, h->ioq, h->qk));
+    CHK(r2c_state(h, d_p0, h->iop, h->pk));
+    CHK(trajectory(h, eps, neps, nullptr));
     CHK(c2r_state(h, h->qk, h->ioq, d_q1));
     CHK(c2r_state(h, h->pk, h->iop, d_p1));
+    return BCHMC_OK;
+  }
+
+  // ---- device-resident chain --------------------------------------------------------------------------------
+  static int chain_alloc(bchmc_handle *h) {
+    if (!h->cq) {
+      CHK(dev_alloc_bytes(h, &h->cq, 2 * (size_t)h->g.Nh * sizeof(T)));
+      CHK(dev_alloc_bytes(h, &h->cp, 2 * (size_t)h->g.Nh * sizeof(T)));
+      CHK(dev_alloc(h, &h->part6, (size_t)6 * kRedBlocks));
+    }
+    return BCHMC_OK;
+  }
+
+  // p ~ N(0, M): coloured white noise, entirely on the device.
+  static int chain_draw(bchmc_handle *h, uint64_t seed, uint64_t attempt) {
+    const long long N = h->g.N, Nh = h->g.Nh;
+    const uint2 key = make_uint2((unsigned)seed, (unsigned)(seed >> 32));
+    ProfScope ps(h, BCHMC_K_OTHER);
+    if (h->mass_fs) {
+      k_white_noise<T><<<nblk_stride((N + 1) / 2), 256, 0, h->stream>>>(N, key, (unsigned)attempt, 0u, nullptr, R(h->iop));
+      HIPCHK(hipGetLastError());
+      CHK(fft_exec(h, h->r2c1, h->iop, h->tC, BCHMC_K_FFT_R2C));
+      k_color_momenta<T><<<nblk_stride(Nh), 256, 0, h->stream>>>(Nh, C(h->tC), h->wM, C(h->cp), 0);
+      HIPCHK(hipGetLastError());
+    } else {
+      HIPCHK(hipMemsetAsync(h->cp, 0, 2 * (size_t)Nh * sizeof(T), h->stream));
+    }
+    if (h->mass_rs) {
+      k_white_noise<T><<<nblk_stride((N + 1) / 2), 256, 0, h->stream>>>(N, key, (unsigned)attempt, 1u,
+                                                                        R(h->in_arr[BCHMC_F_MASS_R]), R(h->iop));
+      HIPCHK(hipGetLastError());
+      CHK(fft_exec(h, h->r2c1, h->iop, h->tC, BCHMC_K_FFT_R2C));
+      k_color_momenta<T><<<nblk_stride(Nh), 256, 0, h->stream>>>(Nh, C(h->tC), nullptr, C(h->cp), 1);
+      HIPCHK(hipGetLastError());
+    }
+    return BCHMC_OK;
+  }
+
+  // Hamiltonian_EoM + delta_Hamiltonian from the resident (q, p).  The proposal stays in (qk, pk).
+  static int chain_attempt(bchmc_handle *h, double eps, uint64_t neps, double terms[6], uint64_t *steps_done) {
+    CHK(check_inputs(h));
+    if (eps > 2.) eps = 2.;
+    const size_t cbytes = 2 * (size_t)h->g.Nh * sizeof(T);
+    const double N = (double)h->g.N;
+    // log_like's forward model equals the force's one iff these hold (gaussian_independent.cpp:57-76 vs
+    // poissonian.cpp:54-56, lognormal_independent.cpp:105-107); otherwise, and for the real-space terms
+    // (GRF likelihood, mass_r kinetic term), fall back to the generic energy evaluation.
+    const bool like_shared = h->c.likelihood == 1 || ((h->c.likelihood == 0 || h->c.likelihood == 2) &&
+                                                       h->c.deltaQ_factor == 1. && !h->c.rsd_model);
+    const bool fast = like_shared && !h->mass_rs && neps >= 1;
+    double *P = h->part6;
+    if (!fast) {
+      CHK(c2r_state(h, h->cq, h->ioq, h->dstage));
+      CHK(c2r_state(h, h->cp, h->iop, h->dstage + h->g.N));
+      CHK(energies_core(h, h->dstage, h->dstage + h->g.N, terms));
+    }
+    HIPCHK(hipMemcpyAsync(h->qk, h->cq, cbytes, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->pk, h->cp, cbytes, hipMemcpyDeviceToDevice, h->stream));
+    if (fast) {
+      k_parseval<T><<<kRedBlocks, 256, 0, h->stream>>>(h->g, C(h->pk), h->wM, P);
+      k_parseval<T><<<kRedBlocks, 256, 0, h->stream>>>(h->g, C(h->qk), h->wS, P + kRedBlocks);
+      HIPCHK(hipGetLastError());
+    }
+    Tap tap{P + 2 * kRedBlocks, P + 5 * kRedBlocks};
+    CHK(trajectory(h, eps, neps, fast ? &tap : nullptr));
+    uint64_t done = 0;
+    if (fast) {
+      k_parseval<T><<<kRedBlocks, 256, 0, h->stream>>>(h->g, C(h->pk), h->wM, P + 3 * kRedBlocks);
+      k_parseval<T><<<kRedBlocks, 256, 0, h->stream>>>(h->g, C(h->qk), h->wS, P + 4 * kRedBlocks);
+      HIPCHK(hipGetLastError());
+      std::vector<double> hp(6 * kRedBlocks);
+      unsigned long long sd = 0;
+      HIPCHK(hipMemcpyAsync(hp.data(), P, hp.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(hipMemcpyAsync(&sd, h->steps_done, sizeof sd, hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(hipStreamSynchronize(h->stream));
+      done = sd;
+      for (int t = 0; t < 6; t++) {
+        double s = 0.;
+        for (int i = 0; i < kRedBlocks; i++) s += hp[(size_t)t * kRedBlocks + i];
+        terms[t] = (t == 0 || t == 1 || t == 3 || t == 4) ? s / (2. * N) : s;
+      }
+      if (done < neps) {
+        // runaway guard fired (HMC.cc:360-364): the tapped forward model is not the final state's; redo it
+        CHK(launch_za(h, h->c.likelihood == 1 ? h->c.deltaQ_factor : 1.));
+        CHK(forward_rest(h, h->c.likelihood == 1 ? h->c.rsd_model : 0));
+        CHK(tap_loglike(h, P));
+        CHK(host_sum(h, P, &terms[5]));
+      }
+    } else {
+      unsigned long long sd = 0;
+      HIPCHK(hipMemcpyAsync(&sd, h->steps_done, sizeof sd, hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(hipStreamSynchronize(h->stream));
+      done = sd;
+      // keep the proposal: energies_core re-transforms into (qk, pk), which reproduces it to round-off
+      CHK(c2r_state(h, h->qk, h->ioq, h->dstage));
+      CHK(c2r_state(h, h->pk, h->iop, h->dstage + h->g.N));
+      CHK(energies_core(h, h->dstage, h->dstage + h->g.N, terms + 3));
+    }
+    if (steps_done) *steps_done = done;
+    h->have_prop = true;
     return BCHMC_OK;
   }
 
@@ -1008,7 +1133,7 @@ void bchmc_destroy(bchmc_handle *h) {
   if (h->info) rocfft_execution_info_destroy(h->info);
   void *ptrs[] = {h->work,  h->wS,       h->wM,    h->qk,    h->pk,   h->gk,     h->Ck,         h->tC,   h->psi,
                   h->V,     h->rho,      h->plike, h->ioq,   h->iop,  h->gprior, h->glike,      h->conv, h->convF,
-                  h->dstage, h->rho_part, h->partA, h->guard, h->stop, h->steps_done, h->hull,  h->t_cnt, h->t_off,
+                  h->dstage, h->cq, h->cp, h->part6, h->rho_part, h->partA, h->guard, h->stop, h->steps_done, h->hull,  h->t_cnt, h->t_off,
                   h->t_woff, h->t_rank,  h->sx,    h->sy,    h->sz,   h->sidx};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
@@ -1128,6 +1253,101 @@ int bchmc_fetch(bchmc_handle *h, bchmc_field field, double *host, size_t n) {
   CHK(DISPATCH(h, fetch(h, field, h->dstage)));
   HIPCHK(hipMemcpyAsync(host, h->dstage, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
+  return BCHMC_OK;
+}
+
+// ---- device-resident chain ------------------------------------------------------------------------------------
+int bchmc_chain_set_state(bchmc_handle *h, const double *q) {
+  if (!h || !q) return BCHMC_ERR_ARG;
+  CHK(DISPATCH(h, chain_alloc(h)));
+  HIPCHK(hipMemcpyAsync(h->dstage, q, h->g.N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  CHK(DISPATCH(h, r2c_state(h, h->dstage, h->ioq, h->cq)));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->have_cq = true;
+  h->have_prop = false;
+  return BCHMC_OK;
+}
+
+int bchmc_chain_set_momenta(bchmc_handle *h, const double *p) {
+  if (!h || !p) return BCHMC_ERR_ARG;
+  CHK(DISPATCH(h, chain_alloc(h)));
+  HIPCHK(hipMemcpyAsync(h->dstage, p, h->g.N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  CHK(DISPATCH(h, r2c_state(h, h->dstage, h->iop, h->cp)));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->have_cp = true;
+  return BCHMC_OK;
+}
+
+int bchmc_chain_draw_momenta(bchmc_handle *h, uint64_t seed, uint64_t attempt) {
+  if (!h) return BCHMC_ERR_ARG;
+  if (h->mass_fs && !h->have[BCHMC_F_MASS_F]) return h->fail(BCHMC_ERR_STATE, "mass_f was never uploaded");
+  if (h->mass_rs && !h->have[BCHMC_F_MASS_R]) return h->fail(BCHMC_ERR_STATE, "mass_r was never uploaded");
+  CHK(DISPATCH(h, chain_alloc(h)));
+  CHK(DISPATCH(h, chain_draw(h, seed, attempt)));
+  h->have_cp = true;
+  return BCHMC_OK;
+}
+
+static int chain_fetch(bchmc_handle *h, const void *xk, double *host) {
+  CHK(DISPATCH(h, c2r_state(h, xk, h->ioq, h->dstage)));
+  HIPCHK(hipMemcpyAsync(host, h->dstage, h->g.N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return BCHMC_OK;
+}
+
+int bchmc_chain_get_state(bchmc_handle *h, double *q) {
+  if (!h || !q) return BCHMC_ERR_ARG;
+  if (!h->have_cq) return h->fail(BCHMC_ERR_STATE, "no chain state set");
+  return chain_fetch(h, h->cq, q);
+}
+
+int bchmc_chain_get_momenta(bchmc_handle *h, double *p) {
+  if (!h || !p) return BCHMC_ERR_ARG;
+  if (!h->have_cp) return h->fail(BCHMC_ERR_STATE, "no momenta set or drawn");
+  return chain_fetch(h, h->cp, p);
+}
+
+int bchmc_chain_get_proposal(bchmc_handle *h, double *q1, double *p1) {
+  if (!h || !q1 || !p1) return BCHMC_ERR_ARG;
+  if (!h->have_prop) return h->fail(BCHMC_ERR_STATE, "no proposal: call bchmc_chain_attempt first");
+  CHK(chain_fetch(h, h->qk, q1));
+  return chain_fetch(h, h->pk, p1);
+}
+
+int bchmc_chain_attempt(bchmc_handle *h, double eps, uint64_t neps, double *dH, double terms[6],
+                        uint64_t *steps_done) {
+  if (!h || !dH || !terms) return BCHMC_ERR_ARG;
+  if (!h->have_cq || !h->have_cp) return h->fail(BCHMC_ERR_STATE, "chain state and momenta must be set first");
+  CHK(DISPATCH(h, chain_attempt(h, eps, neps, terms, steps_done)));
+  const double Hami = terms[0] + (terms[1] + terms[2]);
+  const double Hamf = terms[3] + (terms[4] + terms[5]);
+  double d = Hamf - Hami;
+  if (h->c.div_dH_by_N) d /= (double)h->g.N;  // HMC.cc:234-237
+  *dH = d;
+  return BCHMC_OK;
+}
+
+int bchmc_chain_accept(bchmc_handle *h, int accepted) {
+  if (!h) return BCHMC_ERR_ARG;
+  if (!h->have_prop) return h->fail(BCHMC_ERR_STATE, "no proposal: call bchmc_chain_attempt first");
+  if (accepted) {  // HMC.cc:497-498: copyArray(signalf, hd->x)
+    HIPCHK(hipMemcpyAsync(h->cq, h->qk, 2 * (size_t)h->g.Nh * h->esz, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+  }
+  h->have_prop = false;
+  return BCHMC_OK;
+}
+
+int bchmc_philox_kat(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+  if (!ctr || !key || !out) return BCHMC_ERR_ARG;
+  uint4 *d = nullptr;
+  if (hipMalloc((void **)&d, sizeof(uint4)) != hipSuccess) return BCHMC_ERR_NOMEM;
+  k_philox_kat<<<1, 1>>>(make_uint4(ctr[0], ctr[1], ctr[2], ctr[3]), make_uint2(key[0], key[1]), d);
+  uint4 r;
+  const hipError_t e = hipMemcpy(&r, d, sizeof r, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (e != hipSuccess) return BCHMC_ERR_HIP;
+  out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
   return BCHMC_OK;
 }
 

@@ -57,7 +57,10 @@ _lib = None
 EXPORTS = ("bchmc_create", "bchmc_destroy", "bchmc_strerror", "bchmc_last_error", "bchmc_upload", "bchmc_fetch",
            "bchmc_leapfrog", "bchmc_energies", "bchmc_delta_hamiltonian", "bchmc_gradient", "bchmc_forward",
            "bchmc_leapfrog_device", "bchmc_steps_done", "bchmc_energies_device", "bchmc_sync", "bchmc_stream",
-           "bchmc_profile", "bchmc_profile_read", "bchmc_kernel_name")
+           "bchmc_profile", "bchmc_profile_read", "bchmc_kernel_name",
+           "bchmc_chain_set_state", "bchmc_chain_get_state", "bchmc_chain_set_momenta", "bchmc_chain_get_momenta",
+           "bchmc_chain_draw_momenta", "bchmc_chain_attempt", "bchmc_chain_get_proposal", "bchmc_chain_accept",
+           "bchmc_philox_kat")
 
 
 def load():
@@ -94,8 +97,29 @@ def load():
     lib.bchmc_profile_read.argtypes = [vp, dp, C.POINTER(u64)]
     lib.bchmc_kernel_name.argtypes = [C.c_int]
     lib.bchmc_kernel_name.restype = C.c_char_p
+    lib.bchmc_chain_set_state.argtypes = [vp, dp]
+    lib.bchmc_chain_get_state.argtypes = [vp, dp]
+    lib.bchmc_chain_set_momenta.argtypes = [vp, dp]
+    lib.bchmc_chain_get_momenta.argtypes = [vp, dp]
+    lib.bchmc_chain_draw_momenta.argtypes = [vp, u64, u64]
+    lib.bchmc_chain_attempt.argtypes = [vp, C.c_double, u64, dp, dp, C.POINTER(u64)]
+    lib.bchmc_chain_get_proposal.argtypes = [vp, dp, dp]
+    lib.bchmc_chain_accept.argtypes = [vp, C.c_int]
+    lib.bchmc_philox_kat.argtypes = [C.POINTER(C.c_uint32)] * 3
     _lib = lib
     return lib
+
+
+def philox_kat(ctr, key):
+    """Philox4x32-10 block on the device (known-answer hook)."""
+    lib = load()
+    c = (C.c_uint32 * 4)(*ctr)
+    k = (C.c_uint32 * 2)(*key)
+    o = (C.c_uint32 * 4)()
+    rc = lib.bchmc_philox_kat(c, k, o)
+    if rc:
+        raise BchmcError(rc, lib.bchmc_strerror(rc).decode())
+    return [int(x) for x in o]
 
 
 def make_config(params, device=0, precision=0):
@@ -222,6 +246,40 @@ class Engine:
     @property
     def stream(self):
         return self.lib.bchmc_stream(self.h)
+
+    # ---- device-resident chain ------------------------------------------------
+    def chain_set_state(self, q):
+        self._chk(self.lib.bchmc_chain_set_state(self.h, _p(self._in(q))))
+
+    def chain_get_state(self):
+        q = np.empty(self.N)
+        self._chk(self.lib.bchmc_chain_get_state(self.h, _p(q)))
+        return q
+
+    def chain_set_momenta(self, p):
+        self._chk(self.lib.bchmc_chain_set_momenta(self.h, _p(self._in(p))))
+
+    def chain_get_momenta(self):
+        p = np.empty(self.N)
+        self._chk(self.lib.bchmc_chain_get_momenta(self.h, _p(p)))
+        return p
+
+    def chain_draw_momenta(self, seed, attempt):
+        self._chk(self.lib.bchmc_chain_draw_momenta(self.h, int(seed), int(attempt)))
+
+    def chain_attempt(self, eps, neps):
+        dH, done = C.c_double(), C.c_uint64()
+        terms = np.zeros(6)
+        self._chk(self.lib.bchmc_chain_attempt(self.h, float(eps), int(neps), C.byref(dH), _p(terms), C.byref(done)))
+        return dH.value, terms, done.value
+
+    def chain_get_proposal(self):
+        q1, p1 = np.empty(self.N), np.empty(self.N)
+        self._chk(self.lib.bchmc_chain_get_proposal(self.h, _p(q1), _p(p1)))
+        return q1, p1
+
+    def chain_accept(self, accepted):
+        self._chk(self.lib.bchmc_chain_accept(self.h, int(bool(accepted))))
 
     # ---- measurement ---------------------------------------------------------------------------
     def profile(self, enable):

@@ -106,3 +106,62 @@ def delta_Hamiltonian(hd, signali, momentai, signalf, momentaf):
     n.dE = (n.psi_prior_f + n.psi_likeli_f) - (n.psi_prior_i + n.psi_likeli_i)
     n.dH = float(dH)
     return n.dH
+
+
+def HamiltonianMC(hd, uniform, seed=1, itmax=2000, ring=None, group=None, momenta=None):
+    """One sample of the reference's HamiltonianMC loop (HMC.cc:431-511) on the device-resident chain:
+    repeat { draw momenta; draw (Neps, epsilon); trajectory; dH; Metropolis test } until accepted.
+
+    ``uniform`` stands for ``gsl_rng_uniform`` and is consumed in the reference's order per attempt: Neps, epsilon
+    (HMC.cc:260-261), then the acceptance draw only if p_acc < 1 (HMC.cc:478-480).  Momenta come from the engine's
+    counter-based device generator (``seed``, attempt index) unless ``momenta`` (a callable returning a host
+    array, e.g. a port of the GSL draw) is given.  The chain state must have been set with
+    ``hd.engine.chain_set_state``.  Returns the list of per-attempt records (the performance-log row, HMC.cc:40-60).
+    """
+    n = hd.numerical
+    e = hd.engine
+    log = []
+    for _ in range(itmax):
+        attempt = n.count_attempts
+        if momenta is None:
+            e.chain_draw_momenta(seed, attempt)
+        else:
+            e.chain_set_momenta(momenta())
+        n.Neps = int(n.N_eps_fac * uniform()) + 1
+        n.epsilon = float(n.eps_fac * uniform())
+        if n.epsilon > 2.0:
+            n.epsilon = 2.0
+        dH, t, done = e.chain_attempt(n.epsilon, n.Neps)
+        n.count_attempts += 1
+        n.steps_done = done
+        n.H_kin_i, n.psi_prior_i, n.psi_likeli_i, n.H_kin_f, n.psi_prior_f, n.psi_likeli_f = (float(x) for x in t)
+        n.dprior, n.dlikeli = n.psi_prior_f - n.psi_prior_i, n.psi_likeli_f - n.psi_likeli_i
+        n.dK = n.H_kin_f - n.H_kin_i
+        n.dE = n.dprior + n.dlikeli
+        n.dH = float(dH)
+        # HMC.cc:462-486, statement for statement: a uniform is consumed only when p_acceptance < 1.  (A NaN dH
+        # leaves p_acceptance at 1 there; the reference build traps FE_INVALID before that, main.cc:66-78.)
+        p_acceptance = 1.0
+        if dH < 0.0:
+            p_acceptance = 1.0
+        elif np.exp(-dH) < 1.0:
+            p_acceptance = float(np.exp(-dH))
+        if p_acceptance >= 1.0:
+            accepted = True
+        else:
+            accepted = uniform() < p_acceptance
+        n.accepted = bool(accepted)
+        e.chain_accept(accepted)
+        recs = None
+        if ring is not None:
+            if group is not None:
+                recs = group.record_all(ring, n.epsilon, accepted, n.Neps)
+            else:
+                ring.record(accepted, n.epsilon)
+        log.append(dict(accepted=n.accepted, epsilon=n.epsilon, Neps=n.Neps, dH=n.dH, dK=n.dK, dE=n.dE,
+                        dprior=n.dprior, dlikeli=n.dlikeli, psi_prior_i=n.psi_prior_i, psi_prior_f=n.psi_prior_f,
+                        psi_likeli_i=n.psi_likeli_i, psi_likeli_f=n.psi_likeli_f, H_kin_i=n.H_kin_i,
+                        H_kin_f=n.H_kin_f, steps_done=done, exchanged=recs))
+        if accepted:
+            break
+    return log

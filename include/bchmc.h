@@ -134,6 +134,24 @@ int bchmc_energies_device(bchmc_handle *h, const double *d_q, const double *d_p,
 int bchmc_sync(bchmc_handle *h);
 void *bchmc_stream(bchmc_handle *h); /* hipStream_t the engine launches on */
 
+/* ---- device-resident chain ("next" components, built on the same path) ----
+ * The current sample q and the momenta stay in HBM between attempts, so one HamiltonianMC attempt
+ * (HMC.cc:445-498) costs no 4 x N-double PCIe round trip, and the -log L of both trajectory ends is taken
+ * from the force evaluations the trajectory performs anyway instead of two extra forward models.
+ * Host keeps the control flow: (Neps, epsilon) draws, u < exp(-dH) test, epsilon adaptation. */
+int bchmc_chain_set_state(bchmc_handle *h, const double *q);   /* hd->x -> HBM */
+int bchmc_chain_get_state(bchmc_handle *h, double *q);
+int bchmc_chain_set_momenta(bchmc_handle *h, const double *p); /* host-drawn momenta (reference RNG order) */
+int bchmc_chain_get_momenta(bchmc_handle *h, double *p);
+/* p ~ N(0, M) on the device: counter-based Philox4x32-10, a pure function of (seed, attempt, cell).  Statistical
+ * stand-in for draw_momenta (HMC_momenta.cc:42-94), whose serial GSL stream it does not reproduce. */
+int bchmc_chain_draw_momenta(bchmc_handle *h, uint64_t seed, uint64_t attempt);
+/* Hamiltonian_EoM + delta_Hamiltonian from the resident (q, p); terms as in bchmc_delta_hamiltonian. */
+int bchmc_chain_attempt(bchmc_handle *h, double eps, uint64_t neps, double *dH, double terms[6], uint64_t *steps_done);
+int bchmc_chain_get_proposal(bchmc_handle *h, double *q1, double *p1);
+int bchmc_chain_accept(bchmc_handle *h, int accepted);         /* accepted: q := proposal (HMC.cc:497-498) */
+int bchmc_philox_kat(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]); /* known-answer hook for tests */
+
 /* ---- measurement hooks (bench.py): per-kernel-class HIP-event timing on the engine's stream ---- */
 enum {
   BCHMC_K_FFT_C2R = 0, BCHMC_K_FFT_R2C, BCHMC_K_KSPACE_DRIFT_ZA, BCHMC_K_SCATTER, BCHMC_K_MEAN_PARTIAL,

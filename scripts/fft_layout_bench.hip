@@ -28,9 +28,16 @@ int main(int argc, char **argv) {
   CK(rocfft_setup());
   hipStream_t st; hipStreamCreate(&st);
   const size_t len[3] = {n, n, n};
-  struct Layout { const char *name; size_t row, plane; } layouts[] = {
-      {"contiguous", nh, nh * n}, {"row+7 (136)", nh + 7, (nh + 7) * n}, {"row+7, plane+8 rows", nh + 7, (nh + 7) * (n + 8)},
-      {"row+3 (132)", nh + 3, (nh + 3) * n}, {"row+1 (130), plane+1 row", nh + 1, (nh + 1) * (n + 1)}};
+  struct Layout { char name[64]; size_t row, plane; };
+  std::vector<Layout> layouts;
+  for (size_t pr : {0, 1, 2, 3, 4, 5, 7, 8, 11, 15, 16, 31})
+    for (size_t pp : {0, 1, 4}) {
+      Layout L;
+      L.row = nh + pr;
+      L.plane = L.row * (n + pp);
+      snprintf(L.name, sizeof L.name, "row %zu, plane rows %zu", L.row, n + pp);
+      layouts.push_back(L);
+    }
   for (auto &L : layouts) {
     const size_t cdist = L.plane * n;
     double *R; double2 *C;

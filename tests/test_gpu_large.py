@@ -127,3 +127,22 @@ def test_256_small_step_conserves_energy(big):
     q1, p1, _ = e.leapfrog(f["q0"], f["p0"], eps, 4)
     dH, terms = e.delta_hamiltonian(f["q0"], f["p0"], q1, p1)
     assert abs(dH) < 1e-4 * abs(terms[:3].sum())
+
+
+def test_hundred_step_trajectory_against_oracle():
+    """rel-L2 of (q1, p1) <= 1e-9 at 100 leapfrog steps (BASELINE config 3 length), here on a 32^3 grid
+    the oracle integrates in a few seconds, with Zel'dovich + plane-parallel RSD."""
+    from oracle.oracle import Oracle
+    c = Case(Nx=32, L=100.0, likelihood=1, rsd_model=1, sfmodel=2, eps_scale=0.05)
+    c.oracle.close()
+    o = Oracle(c.p, omp=True)
+    o.set(**c.arrays())
+    e = c.engine()
+    q1o, p1o, done_o = o.Hamiltonian_EoM(c.q0, c.p0, c.eps, 100)
+    q1, p1, done = e.leapfrog(c.q0, c.p0, c.eps, 100)
+    assert done == done_o == 100
+    assert rel_l2(q1, q1o) < 1e-9 and rel_l2(p1, p1o) < 1e-9
+    dHo, to = o.delta_Hamiltonian(c.q0, c.p0, q1o, p1o)
+    dH, t = e.delta_hamiltonian(c.q0, c.p0, q1, p1)
+    assert np.all(np.abs(t - to) <= 1e-8 * np.abs(to))
+    e.close()
