@@ -59,7 +59,10 @@ def test_attempt_after_runaway_guard():
     assert done == 1
     q1o, p1o, _ = c.oracle.Hamiltonian_EoM(c.q0, p0, 1e-6, 5)
     _, to = c.oracle.delta_Hamiltonian(c.q0, p0, q1o, p1o)
-    assert np.all(np.abs(terms - to) <= 1e-8 * np.abs(to))
+    # the final state has displacements ~1e50 cells: its positions (fmod of 1e50) and hence psi_likeli_f are
+    # round-off noise in any implementation; everything else must agree
+    assert np.all(np.abs(terms[:5] - to[:5]) <= 1e-8 * np.abs(to[:5]))
+    assert np.isfinite(terms[5])
     e.close()
 
 
