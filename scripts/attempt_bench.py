@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Time one HamiltonianMC attempt (momenta + trajectory + delta_Hamiltonian) two ways on the GPU box:
+  host-array path:  bchmc_leapfrog + bchmc_delta_hamiltonian with numpy arrays (what the thin reference shim binds),
+  resident chain:   bchmc_chain_draw_momenta + bchmc_chain_attempt + bchmc_chain_accept.
+Usage: python scripts/attempt_bench.py [nx] [neps]"""
+import json
+import sys
+import time
+
+sys.path.insert(0, ".")
+import numpy as np  # noqa: E402
+
+from barcode_amd import inputs  # noqa: E402
+from barcode_amd.engine import Engine  # noqa: E402
+from barcode_amd.params import HamilParams  # noqa: E402
+
+nx = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+neps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+p = HamilParams(Nx=nx, L=200.0, likelihood=1, rsd_model=1, sfmodel=2)
+f = inputs.make_fields(p)
+e = Engine(p)
+e.upload(signal_PS=f["signal_PS"], mass_f=f["mass_f"], nobs=np.zeros(p.N), window=np.ones(p.N), noise=np.ones(p.N))
+e.forward(f["truth"], 1)
+w, s, nobs = inputs.mock_observations(p, e.fetch("deltaX").reshape((nx,) * 3))
+e.upload(window=w, noise=s, nobs=nobs)
+eps = 0.5 * p.eps_heuristic()
+q0, p0 = f["q0"].ravel().copy(), f["p0"].ravel().copy()
+
+
+def host_path():
+    q1, p1, _ = e.leapfrog(q0, p0, eps, neps)
+    return e.delta_hamiltonian(q0, p0, q1, p1)[0]
+
+
+def chain_path(i):
+    e.chain_draw_momenta(1, i)
+    dH, _, _ = e.chain_attempt(eps, neps)
+    e.chain_accept(False)
+    return dH
+
+
+host_path()
+e.chain_set_state(q0)
+chain_path(0)
+reps = 5
+t0 = time.perf_counter()
+for _ in range(reps):
+    host_path()
+t1 = time.perf_counter()
+for i in range(reps):
+    chain_path(i + 1)
+t2 = time.perf_counter()
+print(json.dumps(dict(grid=nx, neps=neps, host_array_ms_per_attempt=1e3 * (t1 - t0) / reps,
+                      resident_chain_ms_per_attempt=1e3 * (t2 - t1) / reps,
+                      note="host path excludes the host-side momentum draw the reference does per attempt")))

@@ -1,0 +1,38 @@
+"""On-disk formats against the reference's OWN fixture: test/data/io_array.dat, the 64-byte file
+its Catch2 known-answer test reads (test/io_array.cpp:81-98).  The file is committed as data under tests/golden/."""
+import os
+
+import numpy as np
+import pytest
+
+from barcode_amd import io as bio
+from tests.util import GOLDEN_DIR
+
+EXPECTED = [18012.18201, 280.22, 300021.850, 3.14, 2., 333888., 807520.20, 170412.0]  # test/io_array.cpp:67-74
+
+
+def test_read_array_reads_the_reference_fixture():
+    a = bio.read_array(os.path.join(GOLDEN_DIR, "reference_io_array"), 8)  # extension added like the reference does
+    assert a.tolist() == EXPECTED
+
+
+def test_write_read_round_trip_and_byte_identity(tmp_path):
+    """test/io_array.cpp:34-59 (round trip), plus: our writer reproduces the reference file byte for byte."""
+    fn = str(tmp_path / "arr")
+    bio.write_array(fn, np.array(EXPECTED))
+    assert os.path.exists(fn + ".dat")
+    assert open(fn + ".dat", "rb").read() == open(os.path.join(GOLDEN_DIR, "reference_io_array.dat"), "rb").read()
+    assert bio.read_array(fn, 8).tolist() == EXPECTED
+    with pytest.raises(RuntimeError):
+        bio.read_array(str(tmp_path / "missing"), 8)
+    with pytest.raises(RuntimeError):
+        bio.read_array(fn, 9)
+    assert bio.add_extension_if_missing("a.b") == "a.b" and bio.add_extension_if_missing("a") == "a.dat"
+
+
+def test_performance_log_schema():
+    assert bio.performance_log_header().split("\t")[0] == "accepted" and len(bio.PERFORMANCE_LOG_COLUMNS) == 14
+    rec = dict(accepted=True, epsilon=0.00123456789, Neps=5, dH=-1.5, dK=2.0, dE=-3.5, dprior=1e-7, dlikeli=-3.5,
+               psi_prior_i=1234567.0, psi_prior_f=1.0, psi_likeli_i=2.0, psi_likeli_f=3.0, H_kin_i=4.0, H_kin_f=5.0)
+    row = bio.performance_log_row(rec).rstrip("\n").split("\t")
+    assert row[:4] == ["1", "0.00123457", "5", "-1.5"] and row[8] == "1.23457e+06" and len(row) == 14
