@@ -916,6 +916,14 @@ struct Pipe {
 
 #define DISPATCH(h, call) ((h)->f32 ? Pipe<float>::call : Pipe<double>::call)
 
+// Every entry point makes the handle's device current first: handles on different GPUs may be driven from one
+// process (one host thread per chain), and HIP launches use the calling thread's current device.
+#define ENTER(h)                                                                                  \
+  do {                                                                                            \
+    hipError_t e_ = hipSetDevice((h)->c.device);                                                  \
+    if (e_ != hipSuccess) return (h)->fail(BCHMC_ERR_HIP, "hipSetDevice(%d): %s", (h)->c.device, hipGetErrorString(e_)); \
+  } while (0)
+
 int validate_config(const bchmc_config *c, std::string &why) {
   char buf[256];
   if (c->abi_version != BCHMC_ABI_VERSION) {
@@ -1125,6 +1133,7 @@ int bchmc_create(const bchmc_config *cfg, bchmc_handle **out) {
 
 void bchmc_destroy(bchmc_handle *h) {
   if (!h) return;
+  (void)hipSetDevice(h->c.device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   prof_collect(h);
   for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
@@ -1150,6 +1159,7 @@ void bchmc_destroy(bchmc_handle *h) {
 
 int bchmc_upload(bchmc_handle *h, bchmc_field field, const double *host, size_t n) {
   if (!h || !host) return BCHMC_ERR_ARG;
+  ENTER(h);
   if ((int)field < 0 || (int)field > BCHMC_F_WINDOW) return h->fail(BCHMC_ERR_ARG, "field %d is not an input", (int)field);
   if (n != (size_t)h->g.N) return h->fail(BCHMC_ERR_ARG, "upload size %zu != N = %lld", n, h->g.N);
   HIPCHK(hipMemcpyAsync(h->dstage, host, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -1161,6 +1171,7 @@ int bchmc_upload(bchmc_handle *h, bchmc_field field, const double *host, size_t 
 
 int bchmc_sync(bchmc_handle *h) {
   if (!h) return BCHMC_ERR_ARG;
+  ENTER(h);
   HIPCHK(hipStreamSynchronize(h->stream));
   return BCHMC_OK;
 }
@@ -1170,11 +1181,13 @@ void *bchmc_stream(bchmc_handle *h) { return h ? (void *)h->stream : nullptr; }
 int bchmc_leapfrog_device(bchmc_handle *h, const double *d_q0, const double *d_p0, double *d_q1, double *d_p1,
                           double eps, uint64_t neps) {
   if (!h || !d_q0 || !d_p0 || !d_q1 || !d_p1) return BCHMC_ERR_ARG;
+  ENTER(h);
   return DISPATCH(h, leapfrog_core(h, d_q0, d_p0, d_q1, d_p1, eps, neps));
 }
 
 int bchmc_steps_done(bchmc_handle *h, uint64_t *steps_done) {
   if (!h || !steps_done) return BCHMC_ERR_ARG;
+  ENTER(h);
   unsigned long long v = 0;
   HIPCHK(hipMemcpyAsync(&v, h->steps_done, sizeof v, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -1185,6 +1198,7 @@ int bchmc_steps_done(bchmc_handle *h, uint64_t *steps_done) {
 int bchmc_leapfrog(bchmc_handle *h, const double *q0, const double *p0, double *q1, double *p1, double eps,
                    uint64_t neps, uint64_t *steps_done) {
   if (!h || !q0 || !p0 || !q1 || !p1) return BCHMC_ERR_ARG;
+  ENTER(h);
   const size_t N = (size_t)h->g.N, bytes = N * sizeof(double);
   double *dq = h->dstage, *dp = h->dstage + N;
   HIPCHK(hipMemcpyAsync(dq, q0, bytes, hipMemcpyHostToDevice, h->stream));
@@ -1200,11 +1214,13 @@ int bchmc_leapfrog(bchmc_handle *h, const double *q0, const double *p0, double *
 
 int bchmc_energies_device(bchmc_handle *h, const double *d_q, const double *d_p, double out[3]) {
   if (!h || !d_q || !d_p || !out) return BCHMC_ERR_ARG;
+  ENTER(h);
   return DISPATCH(h, energies_core(h, d_q, d_p, out));
 }
 
 int bchmc_energies(bchmc_handle *h, const double *q, const double *p, double out[3]) {
   if (!h || !q || !p || !out) return BCHMC_ERR_ARG;
+  ENTER(h);
   const size_t N = (size_t)h->g.N, bytes = N * sizeof(double);
   HIPCHK(hipMemcpyAsync(h->dstage, q, bytes, hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipMemcpyAsync(h->dstage + N, p, bytes, hipMemcpyHostToDevice, h->stream));
@@ -1226,6 +1242,7 @@ int bchmc_delta_hamiltonian(bchmc_handle *h, const double *qi, const double *pi,
 
 int bchmc_forward(bchmc_handle *h, const double *q, int use_rsd) {
   if (!h || !q) return BCHMC_ERR_ARG;
+  ENTER(h);
   if (h->c.likelihood == 3 && h->c.sfmodel != 1 && !h->c.rsd_model)
     return h->fail(BCHMC_ERR_UNSUPPORTED, "sfmodel != 1 forward model is not built");
   HIPCHK(hipMemcpyAsync(h->dstage, q, h->g.N * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -1236,6 +1253,7 @@ int bchmc_forward(bchmc_handle *h, const double *q, int use_rsd) {
 
 int bchmc_gradient(bchmc_handle *h, const double *q, double *gout) {
   if (!h || !q || !gout) return BCHMC_ERR_ARG;
+  ENTER(h);
   CHK(check_inputs(h));
   const size_t N = (size_t)h->g.N;
   HIPCHK(hipMemcpyAsync(h->dstage, q, N * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -1247,6 +1265,7 @@ int bchmc_gradient(bchmc_handle *h, const double *q, double *gout) {
 
 int bchmc_fetch(bchmc_handle *h, bchmc_field field, double *host, size_t n) {
   if (!h || !host) return BCHMC_ERR_ARG;
+  ENTER(h);
   if (n != (size_t)h->g.N) return h->fail(BCHMC_ERR_ARG, "fetch size %zu != N = %lld", n, h->g.N);
   const bool needs_eval = (field >= BCHMC_F_DELTAX && field <= BCHMC_F_PSIZ);
   if (needs_eval && !h->have_eval) return h->fail(BCHMC_ERR_STATE, "no forward evaluation to fetch from");
@@ -1259,6 +1278,7 @@ int bchmc_fetch(bchmc_handle *h, bchmc_field field, double *host, size_t n) {
 // ---- device-resident chain ------------------------------------------------------------------------------------
 int bchmc_chain_set_state(bchmc_handle *h, const double *q) {
   if (!h || !q) return BCHMC_ERR_ARG;
+  ENTER(h);
   CHK(DISPATCH(h, chain_alloc(h)));
   HIPCHK(hipMemcpyAsync(h->dstage, q, h->g.N * sizeof(double), hipMemcpyHostToDevice, h->stream));
   CHK(DISPATCH(h, r2c_state(h, h->dstage, h->ioq, h->cq)));
@@ -1270,6 +1290,7 @@ int bchmc_chain_set_state(bchmc_handle *h, const double *q) {
 
 int bchmc_chain_set_momenta(bchmc_handle *h, const double *p) {
   if (!h || !p) return BCHMC_ERR_ARG;
+  ENTER(h);
   CHK(DISPATCH(h, chain_alloc(h)));
   HIPCHK(hipMemcpyAsync(h->dstage, p, h->g.N * sizeof(double), hipMemcpyHostToDevice, h->stream));
   CHK(DISPATCH(h, r2c_state(h, h->dstage, h->iop, h->cp)));
@@ -1280,6 +1301,7 @@ int bchmc_chain_set_momenta(bchmc_handle *h, const double *p) {
 
 int bchmc_chain_draw_momenta(bchmc_handle *h, uint64_t seed, uint64_t attempt) {
   if (!h) return BCHMC_ERR_ARG;
+  ENTER(h);
   if (h->mass_fs && !h->have[BCHMC_F_MASS_F]) return h->fail(BCHMC_ERR_STATE, "mass_f was never uploaded");
   if (h->mass_rs && !h->have[BCHMC_F_MASS_R]) return h->fail(BCHMC_ERR_STATE, "mass_r was never uploaded");
   CHK(DISPATCH(h, chain_alloc(h)));
@@ -1297,18 +1319,21 @@ static int chain_fetch(bchmc_handle *h, const void *xk, double *host) {
 
 int bchmc_chain_get_state(bchmc_handle *h, double *q) {
   if (!h || !q) return BCHMC_ERR_ARG;
+  ENTER(h);
   if (!h->have_cq) return h->fail(BCHMC_ERR_STATE, "no chain state set");
   return chain_fetch(h, h->cq, q);
 }
 
 int bchmc_chain_get_momenta(bchmc_handle *h, double *p) {
   if (!h || !p) return BCHMC_ERR_ARG;
+  ENTER(h);
   if (!h->have_cp) return h->fail(BCHMC_ERR_STATE, "no momenta set or drawn");
   return chain_fetch(h, h->cp, p);
 }
 
 int bchmc_chain_get_proposal(bchmc_handle *h, double *q1, double *p1) {
   if (!h || !q1 || !p1) return BCHMC_ERR_ARG;
+  ENTER(h);
   if (!h->have_prop) return h->fail(BCHMC_ERR_STATE, "no proposal: call bchmc_chain_attempt first");
   CHK(chain_fetch(h, h->qk, q1));
   return chain_fetch(h, h->pk, p1);
@@ -1317,6 +1342,7 @@ int bchmc_chain_get_proposal(bchmc_handle *h, double *q1, double *p1) {
 int bchmc_chain_attempt(bchmc_handle *h, double eps, uint64_t neps, double *dH, double terms[6],
                         uint64_t *steps_done) {
   if (!h || !dH || !terms) return BCHMC_ERR_ARG;
+  ENTER(h);
   if (!h->have_cq || !h->have_cp) return h->fail(BCHMC_ERR_STATE, "chain state and momenta must be set first");
   CHK(DISPATCH(h, chain_attempt(h, eps, neps, terms, steps_done)));
   const double Hami = terms[0] + (terms[1] + terms[2]);
@@ -1329,6 +1355,7 @@ int bchmc_chain_attempt(bchmc_handle *h, double eps, uint64_t neps, double *dH, 
 
 int bchmc_chain_accept(bchmc_handle *h, int accepted) {
   if (!h) return BCHMC_ERR_ARG;
+  ENTER(h);
   if (!h->have_prop) return h->fail(BCHMC_ERR_STATE, "no proposal: call bchmc_chain_attempt first");
   if (accepted) {  // HMC.cc:497-498: copyArray(signalf, hd->x)
     HIPCHK(hipMemcpyAsync(h->cq, h->qk, 2 * (size_t)h->g.Nh * h->esz, hipMemcpyDeviceToDevice, h->stream));
@@ -1353,6 +1380,7 @@ int bchmc_philox_kat(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[
 
 int bchmc_profile(bchmc_handle *h, int enable) {
   if (!h) return BCHMC_ERR_ARG;
+  ENTER(h);
   HIPCHK(hipStreamSynchronize(h->stream));
   prof_collect(h);
   h->prof_on = enable != 0;
@@ -1361,6 +1389,7 @@ int bchmc_profile(bchmc_handle *h, int enable) {
 
 int bchmc_profile_read(bchmc_handle *h, double ms[BCHMC_K_COUNT], uint64_t launches[BCHMC_K_COUNT]) {
   if (!h) return BCHMC_ERR_ARG;
+  ENTER(h);
   HIPCHK(hipStreamSynchronize(h->stream));
   prof_collect(h);
   for (int i = 0; i < BCHMC_K_COUNT; i++) {

@@ -173,7 +173,7 @@ def main():
     finite = bool(torch.isfinite(q1).all().item() and torch.isfinite(p1).all().item())
 
     # ---- per-kernel HIP-event breakdown (separate, untimed pass) -------------------------------------
-    kernels = None
+    kernels = dominant = None
     if not args.no_kernel_profile:
         ksteps = min(args.steps, 10)
         engine.profile(True)
@@ -183,6 +183,12 @@ def main():
         engine.profile(False)
         kernels = {k: dict(ms_per_step=round(ms / ksteps, 4), launches=n, avg_launch_ms=round(ms / max(n, 1), 4))
                    for k, (ms, n) in prof.items() if n}
+        tot = sum(v["ms_per_step"] for v in kernels.values())
+        dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
+        dominant = dict(name=dom, avg_launch_ms=kernels[dom]["avg_launch_ms"],
+                        share_of_step=round(kernels[dom]["ms_per_step"] / tot, 4),
+                        bound="fp64 vector ALU + LDS atomics (DESIGN.md section 5), not HBM"
+                        if dom in ("k_scatter_sph", "k_gather_sph") else "hbm")
 
     if rank == 0:
         N = params.N
@@ -226,6 +232,7 @@ def main():
                 "traffic_source": traffic_src,
                 "algorithmic_bytes_per_step": algo * N,
                 "device_ms_per_step": round(gpu_ms / args.steps, 4),
+                "dominant_kernel": dominant,
                 "kernels": kernels,
             },
         }
