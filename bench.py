@@ -147,6 +147,7 @@ def main():
     if args.warmup > 0:
         engine.leapfrog_device(q0, p0, q1, p1, eps, args.warmup)
         engine.sync()
+    group.exchange(eps, True, args.warmup)  # untimed: first use of the collective sets up RCCL's channels
     stream = torch.cuda.ExternalStream(engine.stream, device=dev)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
