@@ -29,10 +29,11 @@ __global__ void k_convert(long long n, const A *__restrict__ in, B *__restrict__
 // We precompute that factor once per upload on the half-complex layout (always double: it is a k-space weight).
 // ------------------------------------------------------------------------------------------------------
 __global__ void k_prepare_mult(Geo g, const double *__restrict__ corr, double *__restrict__ mult, double normFS) {
-  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < g.Nh;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < g.Nhp;
        idx += (long long)gridDim.x * blockDim.x) {
-    const int k = (int)(idx % g.nh);
-    const long long ij = idx / g.nh;
+    const int k = (int)(idx % g.nhp);
+    if (k >= g.nh) continue;   // row padding stays zero
+    const long long ij = idx / g.nhp;
     const double c = corr[k + (long long)g.n * ij];
     mult[idx] = (c > 0.0) ? normFS / c : 0.;
   }
@@ -76,8 +77,9 @@ k_kick_drift_za(Geo g, C2<T> *__restrict__ qk, C2<T> *__restrict__ pk, const C2<
       return;  // NB: *stop is only read by LATER kernels, every thread of this one takes this branch
     }
   }
-  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < g.Nh;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < g.Nhp;
        idx += (long long)gridDim.x * blockDim.x) {
+    const int k = (int)(idx % g.nhp);
     double2 q = ld2<T>(qk, idx);
     if (DRIFT) {
       double2 p = ld2<T>(pk, idx);
@@ -100,8 +102,7 @@ k_kick_drift_za(Geo g, C2<T> *__restrict__ qk, C2<T> *__restrict__ pk, const C2<
       q.y += eps * v.y;
       st2<T>(qk, idx, q.x, q.y);
     }
-    const int k = (int)(idx % g.nh);
-    const long long ij = idx / g.nh;
+    const long long ij = idx / g.nhp;
     const int j = (int)(ij % g.n), i = (int)(ij / g.n);
     const double kx = kval(i, g.n, g.kfac), ky = kval(j, g.n, g.kfac), kz = kval(k, g.n, g.kfac);
     const double ksq = kx * kx + ky * ky + kz * kz;
@@ -116,8 +117,8 @@ k_kick_drift_za(Geo g, C2<T> *__restrict__ qk, C2<T> *__restrict__ pk, const C2<
       oz = make_double2(fz * pi, fz * -pr);
     }
     st2<T>(Ck, idx, ox.x, ox.y);
-    st2<T>(Ck, idx + g.Nh, oy.x, oy.y);
-    st2<T>(Ck, idx + 2 * g.Nh, oz.x, oz.y);
+    st2<T>(Ck, idx + g.Nhp, oy.x, oy.y);
+    st2<T>(Ck, idx + 2 * g.Nhp, oz.x, oz.y);
   }
 }
 
@@ -485,19 +486,19 @@ k_assemble(Geo g, const C2<T> *__restrict__ Ck, const C2<T> *__restrict__ qk, co
   __shared__ double red[4];
   if (KICK && *stop) return;
   double gsum = 0.;
-  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < g.Nh;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < g.Nhp;
        idx += (long long)gridDim.x * blockDim.x) {
-    const int k = (int)(idx % g.nh);
+    const int k = (int)(idx % g.nhp);
     double2 hk = make_double2(0., 0.);
     if (like_mode == 0) {
-      const long long ij = idx / g.nh;
+      const long long ij = idx / g.nhp;
       const int j = (int)(ij % g.n), i = (int)(ij / g.n);
       const bool nyq = (i == g.n / 2) || (j == g.n / 2) || (k == g.n / 2);
       const double kx = kval(i, g.n, g.kfac), ky = kval(j, g.n, g.kfac), kz = kval(k, g.n, g.kfac);
       const double kmod = kx * kx + ky * ky + kz * kz;
       if (kmod > 0 && !nyq) {
         const double f = 1 / kmod;
-        const double2 vx = ld2<T>(Ck, idx), vy = ld2<T>(Ck, idx + g.Nh), vz = ld2<T>(Ck, idx + 2 * g.Nh);
+        const double2 vx = ld2<T>(Ck, idx), vy = ld2<T>(Ck, idx + g.Nhp), vz = ld2<T>(Ck, idx + 2 * g.Nhp);
         const double fx = kx * f, fy = ky * f, fz = kz * f;
         hk.x = fx * vx.y + fy * vy.y + fz * vz.y;
         hk.y = -(fx * vx.x) - fy * vy.x - fz * vz.x;
@@ -519,7 +520,7 @@ k_assemble(Geo g, const C2<T> *__restrict__ Ck, const C2<T> *__restrict__ qk, co
       p.y -= c_kick * gg.y;
       st2<T>(pk, idx, p.x, p.y);
       const double hw = (k == 0 || ((g.n & 1) == 0 && k == g.n / 2)) ? 1. : 2.;
-      gsum += hw * p.x;
+      if (k < g.nh) gsum += hw * p.x;
     }
   }
   if (KICK) {
@@ -535,12 +536,12 @@ __global__ void __launch_bounds__(256)
 k_parseval(Geo g, const C2<T> *__restrict__ xk, const double *__restrict__ w, double *__restrict__ partials) {
   __shared__ double red[4];
   double s = 0.;
-  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < g.Nh;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < g.Nhp;
        idx += (long long)gridDim.x * blockDim.x) {
-    const int k = (int)(idx % g.nh);
+    const int k = (int)(idx % g.nhp);
     const double hw = (k == 0 || ((g.n & 1) == 0 && k == g.n / 2)) ? 1. : 2.;
     const double2 x = ld2<T>(xk, idx);
-    s += hw * w[idx] * (x.x * x.x + x.y * x.y);
+    if (k < g.nh) s += hw * w[idx] * (x.x * x.x + x.y * x.y);
   }
   s = block_sum(s, red);
   if (threadIdx.x == 0) partials[blockIdx.x] = s;
@@ -700,18 +701,18 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 k_conv_kernel(Geo g, const C2<T> *__restrict__ pl, const double *__restrict__ F, C2<T> *__restrict__ Ck, double hh,
               double inv_n) {
-  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < g.Nh;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < g.Nhp;
        idx += (long long)gridDim.x * blockDim.x) {
-    const int k = (int)(idx % g.nh);
-    const long long ij = idx / g.nh;
+    const int k = (int)(idx % g.nhp);
+    const long long ij = idx / g.nhp;
     const int j = (int)(ij % g.n), i = (int)(ij / g.n);
     const double kx = kval(i, g.n, g.kfac), ky = kval(j, g.n, g.kfac), kz = kval(k, g.n, g.kfac);
     const double f = F[idx];
     const double2 v = ld2<T>(pl, idx);
     // re = h * k_j * -Im(pl) * F, im = h * k_j * Re(pl) * F  (HMC_models_testing.cpp:117-130), then / N
     st2<T>(Ck, idx, hh * kx * -v.y * f * inv_n, hh * kx * v.x * f * inv_n);
-    st2<T>(Ck, idx + g.Nh, hh * ky * -v.y * f * inv_n, hh * ky * v.x * f * inv_n);
-    st2<T>(Ck, idx + 2 * g.Nh, hh * kz * -v.y * f * inv_n, hh * kz * v.x * f * inv_n);
+    st2<T>(Ck, idx + g.Nhp, hh * ky * -v.y * f * inv_n, hh * ky * v.x * f * inv_n);
+    st2<T>(Ck, idx + 2 * g.Nhp, hh * kz * -v.y * f * inv_n, hh * kz * v.x * f * inv_n);
   }
 }
 
@@ -777,10 +778,10 @@ k_interp_tsc(Geo g, PosPar pp, double f1, const T *__restrict__ psi, const T *__
 template <typename T>
 __global__ void __launch_bounds__(256)
 k_gradfft_mult(Geo g, const C2<T> *__restrict__ fk, C2<T> *__restrict__ Ck, double inv_n) {
-  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < g.Nh;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < g.Nhp;
        idx += (long long)gridDim.x * blockDim.x) {
-    const int k = (int)(idx % g.nh);
-    const long long ij = idx / g.nh;
+    const int k = (int)(idx % g.nhp);
+    const long long ij = idx / g.nhp;
     const int j = (int)(ij % g.n), i = (int)(ij / g.n);
     const bool nyq = (i == g.n / 2) || (j == g.n / 2) || (k == g.n / 2);
     const double2 v = ld2<T>(fk, idx);
@@ -788,9 +789,9 @@ k_gradfft_mult(Geo g, const C2<T> *__restrict__ fk, C2<T> *__restrict__ Ck, doub
 #pragma unroll
     for (int c = 0; c < 3; c++) {
       if (nyq)
-        st2<T>(Ck, idx + c * g.Nh, 0., 0.);
+        st2<T>(Ck, idx + c * g.Nhp, 0., 0.);
       else
-        st2<T>(Ck, idx + c * g.Nh, -kk[c] * v.y * inv_n, kk[c] * v.x * inv_n);
+        st2<T>(Ck, idx + c * g.Nhp, -kk[c] * v.y * inv_n, kk[c] * v.x * inv_n);
     }
   }
 }

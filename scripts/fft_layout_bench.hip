@@ -24,6 +24,8 @@ static double time_plan(rocfft_plan plan, void *in, void *out, hipStream_t st, r
 
 int main(int argc, char **argv) {
   const size_t n = argc > 1 ? atoi(argv[1]) : 256;
+  const bool f32 = argc > 2 && atoi(argv[2]) == 32;
+  const size_t esz = f32 ? 4 : 8;
   const size_t nh = n / 2 + 1;
   CK(rocfft_setup());
   hipStream_t st; hipStreamCreate(&st);
@@ -41,10 +43,10 @@ int main(int argc, char **argv) {
   for (auto &L : layouts) {
     const size_t cdist = L.plane * n;
     double *R; double2 *C;
-    hipMalloc(&R, 3 * n * n * n * sizeof(double));
-    hipMalloc(&C, 3 * cdist * sizeof(double2));
-    hipMemset(R, 0, 3 * n * n * n * sizeof(double));
-    hipMemset(C, 0, 3 * cdist * sizeof(double2));
+    hipMalloc(&R, 3 * n * n * n * esz);
+    hipMalloc(&C, 3 * cdist * 2 * esz);
+    hipMemset(R, 0, 3 * n * n * n * esz);
+    hipMemset(C, 0, 3 * cdist * 2 * esz);
     for (int dir = 0; dir < 2; dir++) {
       rocfft_plan_description d; CK(rocfft_plan_description_create(&d));
       size_t rstr[3] = {1, n, n * n}, cstr[3] = {1, L.row, L.plane};
@@ -57,14 +59,14 @@ int main(int argc, char **argv) {
       rocfft_plan plan;
       CK(rocfft_plan_create(&plan, rocfft_placement_notinplace,
                             dir == 0 ? rocfft_transform_type_real_forward : rocfft_transform_type_real_inverse,
-                            rocfft_precision_double, 3, len, 3, d));
+                            f32 ? rocfft_precision_single : rocfft_precision_double, 3, len, 3, d));
       size_t wb = 0; CK(rocfft_plan_get_work_buffer_size(plan, &wb));
       void *work = nullptr; if (wb) hipMalloc(&work, wb);
       rocfft_execution_info info; CK(rocfft_execution_info_create(&info));
       CK(rocfft_execution_info_set_stream(info, st));
       if (wb) CK(rocfft_execution_info_set_work_buffer(info, work, wb));
       const double ms = dir == 0 ? time_plan(plan, R, C, st, info, 20) : time_plan(plan, C, R, st, info, 20);
-      printf("n=%zu %-26s %s batch3: %.3f ms (work buffer %.1f MB)\n", n, L.name, dir == 0 ? "R2C" : "C2R", ms, wb / 1e6);
+      printf("%s n=%zu %-26s %s batch3: %.3f ms (work buffer %.1f MB)\n", f32 ? "f32" : "f64", n, L.name, dir == 0 ? "R2C" : "C2R", ms, wb / 1e6);
       rocfft_plan_destroy(plan); rocfft_execution_info_destroy(info); rocfft_plan_description_destroy(d);
       if (work) hipFree(work);
     }

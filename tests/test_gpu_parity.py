@@ -249,6 +249,41 @@ def test_direct_kernels_when_tiling_is_disabled(monkeypatch):
     e.close()
 
 
+@pytest.mark.parametrize("kw", [
+    dict(likelihood=1, rsd_model=1),
+    dict(likelihood=1, rsd_model=0, calc_h=3),
+    dict(likelihood=1, rsd_model=0, calc_h=0),
+    dict(likelihood=0, rsd_model=1, mass_type=5),
+    dict(likelihood=3, rsd_model=0),
+    dict(likelihood=1, rsd_model=1, precision=1),
+], ids=["gauss_rsd", "calc_h3", "calc_h0", "mass5", "grf", "fp32"])
+def test_padded_half_complex_rows(monkeypatch, kw):
+    """BCHMC_FFT_PAD=1 forces the padded row stride of the half-complex arrays (default only for n >= 128) at 16^3:
+    every k-space kernel must skip the padding and the rocFFT plans must use the strided layout."""
+    monkeypatch.setenv("BCHMC_FFT_PAD", "1")
+    kw = dict(kw)
+    f32 = kw.pop("precision", 0) == 1
+    c = Case(Nx=16, **kw)
+    e = c.engine(precision=1) if f32 else c.engine()
+    tf, tt, te = (TOL_F32_FIELD * 10, TOL_F32_TRAJ, TOL_F32_ENERGY) if f32 else (10 * TOL_FIELD, TOL_TRAJ_10, TOL_ENERGY)
+    g, _, _ = c.oracle.gradient_psi(c.q0)
+    assert rel_l2(e.gradient(c.q0), g) < tf
+    q1o, p1o, _ = c.oracle.Hamiltonian_EoM(c.q0, c.p0, c.eps, 5)
+    q1, p1, done = e.leapfrog(c.q0, c.p0, c.eps, 5)
+    assert done == 5
+    assert rel_l2(q1, q1o) < tt and rel_l2(p1, p1o) < tt
+    dHo, to = c.oracle.delta_Hamiltonian(c.q0, c.p0, q1o, p1o)
+    dH, t = e.delta_hamiltonian(c.q0, c.p0, q1o, p1o)
+    assert np.all(np.abs(t - to) <= te * np.abs(to))
+    if not f32:
+        # resident chain: tapped energies of the same trajectory
+        e.chain_set_state(c.q0)
+        e.chain_set_momenta(c.p0)
+        dHc, tc, donec = e.chain_attempt(c.eps, 5)
+        assert donec == 5 and np.all(np.abs(tc - to) <= 1e-8 * np.abs(to).max())
+    e.close()
+
+
 def test_device_resident_entry_points():
     """bchmc_leapfrog_device / bchmc_energies_device on torch tensors give the host-array results."""
     import torch
