@@ -86,6 +86,7 @@ struct bchmc_handle {
   bool hull_exact = false;  // no cell of the (2 reach + 1)^3 cube outside the hull can pass r/h <= 2
   // tile-sorted particle-mesh path
   bool tiled = false;
+  bool std81 = false;  // standard 81-cell hull on 8 x 8 x 16 tiles with halo 2: fully unrolled scatter/gather kernels
   TilePar tp{};
   int *t_cnt = nullptr, *t_off = nullptr, *t_woff = nullptr;  // ntiles, ntiles+1, ntiles+1
   int2 *t_rank = nullptr;                                      // N
@@ -140,6 +141,12 @@ int dev_alloc_bytes(bchmc_handle *h, void **p, size_t bytes) {
 template <typename U>
 int dev_alloc(bchmc_handle *h, U **p, size_t count) {
   return dev_alloc_bytes(h, (void **)p, count * sizeof(U));
+}
+
+// Debug/A-B switches: set to 1 to enable (unset or 0 = off).
+inline bool env_on(const char *name) {
+  const char *v = std::getenv(name);
+  return v && v[0] == '1';
 }
 
 inline int nblk_stride(long long n) { return (int)std::min<long long>((n + 255) / 256, 2048); }
@@ -412,10 +419,14 @@ struct Pipe {
       if (h->c.mk == 3 && h->tiled) {
         const int grid = h->tp.ntiles + (int)(h->g.N / h->tp.chunk) + 1;  // upper bound on (tile, chunk) work items
         const int ncol = h->hull_exact ? h->hull_n : 0;
-        const int reorder = (h->tp.chunk == 2048 && !std::getenv("BCHMC_NO_SUBSORT")) ? 1 : 0;
-        k_scatter_tile<T><<<grid, 256, tile_lds(h, ncol, sizeof(double)), h->stream>>>(h->g, sp, h->tp, h->hull, ncol, reorder, R(h->sx),
-                                                                       R(h->sy), R(h->sz), h->sidx, h->t_off, h->t_woff,
-                                                                       R(h->rho));
+        const int reorder = (h->tp.chunk == 2048 && !env_on("BCHMC_NO_SUBSORT")) ? 1 : 0;
+        if (h->std81)
+          k_scatter_tile81<T, 12, 20><<<grid, 256, tile_lds(h, 0, sizeof(double)), h->stream>>>(
+              h->g, sp, h->tp, reorder, R(h->sx), R(h->sy), R(h->sz), h->sidx, h->t_off, h->t_woff, R(h->rho));
+        else
+          k_scatter_tile<T><<<grid, 256, tile_lds(h, ncol, sizeof(double)), h->stream>>>(
+              h->g, sp, h->tp, h->hull, ncol, reorder, R(h->sx), R(h->sy), R(h->sz), h->sidx, h->t_off, h->t_woff,
+              R(h->rho));
       } else if (h->c.mk == 3) {
         k_scatter_sph<T><<<nblk_full(h->g.N), 256, 0, h->stream>>>(h->g, pp, sp, R(h->psi), R(h->rho));
       } else if (h->c.mk >= 0 && h->c.mk <= 2) {
@@ -515,9 +526,14 @@ struct Pipe {
       HullPar hp = make_hull(h);
       if (h->tiled && h->sorted_valid) {
         const int grid = h->tp.ntiles + (int)(N / h->tp.chunk) + 1;
-        k_gather_tile<T><<<grid, 256, tile_lds(h, hp.ncol, sizeof(T)), h->stream>>>(h->g, hp, h->tp, h->last_rsd, R(h->sx),
-                                                                         R(h->sy), R(h->sz), h->sidx, h->t_off,
-                                                                         h->t_woff, R(h->plike), R(h->V));
+        if (h->std81)
+          k_gather_tile81<T, 12, 20><<<grid, 256, tile_lds(h, 0, sizeof(T)), h->stream>>>(
+              h->g, hp, h->tp, h->last_rsd, R(h->sx), R(h->sy), R(h->sz), h->sidx, h->t_off, h->t_woff, R(h->plike),
+              R(h->V));
+        else
+          k_gather_tile<T><<<grid, 256, tile_lds(h, hp.ncol, sizeof(T)), h->stream>>>(
+              h->g, hp, h->tp, h->last_rsd, R(h->sx), R(h->sy), R(h->sz), h->sidx, h->t_off, h->t_woff, R(h->plike),
+              R(h->V));
       } else {
         k_gather_sph<T><<<nblk_full(N), 256, hp.ncol * sizeof(int4), h->stream>>>(h->g, make_pos(h, h->last_rsd), hp,
                                                                                   R(h->psi), R(h->plike), R(h->V));
@@ -1117,7 +1133,7 @@ int bchmc_create(const bchmc_config *cfg, bchmc_handle **out) {
       const int n = g.n;
       tp.tx = tp.ty = (n % 8 == 0) ? 8 : ((n % 4 == 0) ? 4 : 0);
       tp.tz = (n % 16 == 0) ? 16 : tp.tx;
-      const bool want = (cfg->mk == 3) && tp.tx > 0 && !std::getenv("BCHMC_NO_TILES");
+      const bool want = (cfg->mk == 3) && tp.tx > 0 && !env_on("BCHMC_NO_TILES");
       if (want) {
         tp.ntx = n / tp.tx;
         tp.nty = n / tp.ty;
@@ -1134,6 +1150,13 @@ int bchmc_create(const bchmc_config *cfg, bchmc_handle **out) {
         const size_t lds = (size_t)tp.lx * tp.ly * tp.lz * sizeof(double) + cols.size() * sizeof(int4) + 128;
         if (lds <= 64 * 1024 && g.N < (1ll << 30)) {
           h->tiled = true;
+          // the unrolled kernels hard-code this stencil and tile shape
+          bool is81 = h->hull_exact && cols.size() == 21 && tp.tx == 8 && tp.ty == 8 && tp.tz == 16 && tp.R == 2;
+          for (auto &c : cols) {
+            const int zw = (std::abs(c.x) <= 2 && std::abs(c.y) <= 2) ? hull81_zw(c.x + 2, c.y + 2) : -1;
+            if (zw < 0 || c.z != -zw || c.w != zw) is81 = false;
+          }
+          h->std81 = is81 && !env_on("BCHMC_NO_UNROLL");
           CHK(dev_alloc(h, &h->t_cnt, (size_t)tp.ntiles));
           CHK(dev_alloc(h, &h->t_off, (size_t)tp.ntiles + 1));
           CHK(dev_alloc(h, &h->t_woff, (size_t)tp.ntiles + 1));

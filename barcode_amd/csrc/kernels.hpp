@@ -1097,6 +1097,55 @@ __device__ __forceinline__ bool tile_work(const TilePar &tp, const int *__restri
   return tile >= 0;
 }
 
+// Order one work item's records by the octant of the particle's sub-cell offset (in place; the gather reads the
+// same order).  The 64 lanes of a wave then share the set of stencil cells that can pass the `r/h <= 2` test
+// (51 instead of 81 on average), and a wave pays for every candidate ANY of its lanes needs.  Pure reordering:
+// results do not depend on it.  Requires chunk == 256 * 8 and blockDim.x == 256.
+template <typename T>
+__device__ __forceinline__ void subsort_octants(int pb, int pe, T d, T *sx, T *sy, T *sz, int *sidx) {
+  constexpr int kPer = 8;  // tp.chunk == 256 * kPer
+  __shared__ int hist[8], base[8];
+  if (threadIdx.x < 8) hist[threadIdx.x] = 0;
+  __syncthreads();
+  T rx[kPer], ry[kPer], rz[kPer];
+  int id[kPer], key[kPer], rank[kPer];
+#pragma unroll
+  for (int m = 0; m < kPer; m++) {
+    const int s = pb + (int)threadIdx.x + 256 * m;
+    if (s < pe) {
+      rx[m] = sx[s];
+      ry[m] = sy[s];
+      rz[m] = sz[s];
+      id[m] = sidx[s];
+      const T fx = rx[m] / d, fy = ry[m] / d, fz = rz[m] / d;
+      key[m] = (((fx - r_floor(fx)) >= T(0.5)) << 2) | (((fy - r_floor(fy)) >= T(0.5)) << 1) |
+               ((fz - r_floor(fz)) >= T(0.5));
+      rank[m] = atomicAdd(&hist[key[m]], 1);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int acc = 0;
+    for (int b = 0; b < 8; b++) {
+      base[b] = acc;
+      acc += hist[b];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < kPer; m++) {
+    const int s = pb + (int)threadIdx.x + 256 * m;
+    if (s < pe) {
+      const int dst = pb + base[key[m]] + rank[m];
+      sx[dst] = rx[m];
+      sy[dst] = ry[m];
+      sz[dst] = rz[m];
+      sidx[dst] = id[m];
+    }
+  }
+  __threadfence_block();
+}
+
 // getDensity_SPH on sorted particles: LDS accumulation per (tile, chunk), one flush.
 template <typename T>
 __global__ void __launch_bounds__(256)
@@ -1111,53 +1160,7 @@ k_scatter_tile(Geo g, SphPar sp, TilePar tp, const int4 *__restrict__ cols, int 
   for (int m = threadIdx.x; m < ncol; m += blockDim.x) s_cols[m] = cols[m];
   for (int c = threadIdx.x; c < ncell; c += blockDim.x) s_tile_acc[c] = 0.;
   const T d = (T)g.d;
-  // Prologue: order this work item's records by the octant of the particle's sub-cell offset (in place, for
-  // the gather kernel too).  The 64 lanes of a wave then share the set of stencil cells that can pass the
-  // `r/h <= 2` test (51 instead of 81 on average), and a wave pays for every candidate ANY of its lanes needs.
-  // Pure reordering: results do not depend on it.
-  if (reorder) {
-    constexpr int kPer = 8;  // tp.chunk == 256 * kPer
-    __shared__ int hist[8], base[8];
-    if (threadIdx.x < 8) hist[threadIdx.x] = 0;
-    __syncthreads();
-    T rx[kPer], ry[kPer], rz[kPer];
-    int id[kPer], key[kPer], rank[kPer];
-#pragma unroll
-    for (int m = 0; m < kPer; m++) {
-      const int s = pb + (int)threadIdx.x + 256 * m;
-      if (s < pe) {
-        rx[m] = sx[s];
-        ry[m] = sy[s];
-        rz[m] = sz[s];
-        id[m] = sidx[s];
-        const T fx = rx[m] / d, fy = ry[m] / d, fz = rz[m] / d;
-        key[m] = (((fx - r_floor(fx)) >= T(0.5)) << 2) | (((fy - r_floor(fy)) >= T(0.5)) << 1) |
-                 ((fz - r_floor(fz)) >= T(0.5));
-        rank[m] = atomicAdd(&hist[key[m]], 1);
-      }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      int acc = 0;
-      for (int b = 0; b < 8; b++) {
-        base[b] = acc;
-        acc += hist[b];
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int m = 0; m < kPer; m++) {
-      const int s = pb + (int)threadIdx.x + 256 * m;
-      if (s < pe) {
-        const int dst = pb + base[key[m]] + rank[m];
-        sx[dst] = rx[m];
-        sy[dst] = ry[m];
-        sz[dst] = rz[m];
-        sidx[dst] = id[m];
-      }
-    }
-    __threadfence_block();
-  }
+  if (reorder) subsort_octants<T>(pb, pe, d, sx, sy, sz, sidx);
   __syncthreads();
   const int tzi = tile % tp.ntz, tyi = (tile / tp.ntz) % tp.nty, txi = tile / (tp.ntz * tp.nty);
   const int ox = txi * tp.tx - tp.R, oy = tyi * tp.ty - tp.R, oz = tzi * tp.tz - tp.R;  // global cell of LDS (0,0,0)
@@ -1272,6 +1275,164 @@ k_gather_tile(Geo g, HullPar hp, TilePar tp, int rsd, const T *__restrict__ sx, 
           vz += common * zh;
         }
         zh -= d_h;
+      }
+    }
+    const T normalize = (T)hp.normalize;
+    vx *= normalize;
+    vy *= normalize;
+    vz *= normalize;
+    if (rsd) vz += (T)hp.f1 * vz;
+    const long long p = sidx[s] & ~kSortFlagNoScatter;
+    V[p] = vx;
+    V[p + g.N] = vy;
+    V[p + 2 * g.N] = vz;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Specialisations for the standard stencil (h = d: the 81-cell hull of SPH_kernel_3D_cells_hull_1,
+// SPH_kernel.cpp:110-139) on 8 x 8 x 16 tiles with a 2-cell halo.  The hull and the LDS tile shape are compile-time
+// constants, so the column/cell loops unroll completely: the squared axis offsets are computed once per particle
+// (r^2 = X[a] + Y[b] + Z[c], one add per candidate instead of convert + fma + subtract + fma), every LDS access
+// has an immediate offset, and a rejected candidate costs add + compare + branch.  Same (particle, cell) pairs
+// and the same kernel evaluations as the generic kernels above; r^2 differs from theirs by rounding only.
+// ------------------------------------------------------------------------------------------------------
+// z half-width of hull column (a - 2, b - 2): -1 = not in the hull
+__host__ __device__ constexpr int hull81_zw(int a, int b) {
+  const int i1 = a < 2 ? 2 - a : a - 2, i2 = b < 2 ? 2 - b : b - 2;
+  return (i1 == 2 && i2 == 2) ? -1 : ((i1 == 2 || i2 == 2) ? 1 : 2);
+}
+
+template <typename T, int LY, int LZ>
+__global__ void __launch_bounds__(256)
+k_scatter_tile81(Geo g, SphPar sp, TilePar tp, int reorder, T *sx, T *sy, T *sz, int *sidx,
+                 const int *__restrict__ off, const int *__restrict__ woff, T *__restrict__ rho) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw_scatter81[];
+  double *s_tile_acc = reinterpret_cast<double *>(s_raw_scatter81);
+  int tile, pb, pe;
+  if (!tile_work(tp, off, woff, tile, pb, pe)) return;
+  const int ncell = tp.lx * LY * LZ;
+  for (int c = threadIdx.x; c < ncell; c += blockDim.x) s_tile_acc[c] = 0.;
+  const T d = (T)g.d;
+  if (reorder) subsort_octants<T>(pb, pe, d, sx, sy, sz, sidx);
+  __syncthreads();
+  const int tzi = tile % tp.ntz, tyi = (tile / tp.ntz) % tp.nty, txi = tile / (tp.ntz * tp.nty);
+  const int ox = txi * tp.tx - 2, oy = tyi * tp.ty - 2, oz = tzi * tp.tz - 2;  // global cell of LDS (0,0,0)
+  const int n = g.n;
+  const T r2_lim = (T)sp.r2_lim, h_inv = (T)sp.h_inv, w_norm = (T)sp.w_norm;
+  for (int s = pb + threadIdx.x; s < pe; s += blockDim.x) {
+    if (sidx[s] & kSortFlagNoScatter) continue;
+    const T x = sx[s], y = sy[s], z = sz[s];
+    const long long ix = home_cell(x, d), iy = home_cell(y, d), iz = home_cell(z, d);
+    const T ccx = ((T)ix + T(0.5)) * d, ccy = ((T)iy + T(0.5)) * d, ccz = ((T)iz + T(0.5)) * d;
+    const int hx = (int)(ix % n) - ox, hy = (int)(iy % n) - oy, hz = (int)(iz % n) - oz;  // home cell in LDS coords
+    if ((unsigned)(hx - 2) >= (unsigned)tp.tx || (unsigned)(hy - 2) >= (unsigned)tp.ty ||
+        (unsigned)(hz - 2) >= (unsigned)tp.tz)
+      continue;  // cannot happen (binning and this kernel see the same stored position); keeps LDS indexing safe
+    T X[5], Y[5], Z[5];
+#pragma unroll
+    for (int a = 0; a < 5; a++) {
+      const T dx = x - (ccx + (T)(a - 2) * d), dy = y - (ccy + (T)(a - 2) * d), dz = z - (ccz + (T)(a - 2) * d);
+      X[a] = dx * dx;
+      Y[a] = dy * dy;
+      Z[a] = dz * dz;
+    }
+    double *corner = s_tile_acc + LZ * ((hy - 2) + LY * (hx - 2)) + (hz - 2);
+#pragma unroll
+    for (int a = 0; a < 5; a++) {
+#pragma unroll
+      for (int b = 0; b < 5; b++) {
+        const int zw = hull81_zw(a, b);  // folds after unrolling
+        if (zw < 0) continue;
+        const T r2ab = X[a] + Y[b];
+        if (r2ab > r2_lim) continue;
+        double *row = corner + LZ * (b + LY * a);
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+          if (c < 2 - zw || c > 2 + zw) continue;
+          const T r2 = r2ab + Z[c];
+          if (r2 <= r2_lim) {
+            const T q = (r2 * fast_rsqrt(r_max(r2, tiny_pos<T>()))) * h_inv;
+            if (q <= T(2)) atomic_add_r(row + c, (double)sph_w_sel<T>(q, w_norm));
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < ncell; c += blockDim.x) {
+    const double v = s_tile_acc[c];
+    if (v != 0.) {
+      const int cz = c % LZ, cy = (c / LZ) % LY, cx = c / (LZ * LY);
+      const int gx = (ox + cx + n) % n, gy = (oy + cy + n) % n, gz = (oz + cz + n) % n;
+      atomic_add_r(rho + gz + (long long)n * (gy + (long long)n * gx), (T)v);
+    }
+  }
+}
+
+template <typename T, int LY, int LZ>
+__global__ void __launch_bounds__(256)
+k_gather_tile81(Geo g, HullPar hp, TilePar tp, int rsd, const T *__restrict__ sx, const T *__restrict__ sy,
+                const T *__restrict__ sz, const int *__restrict__ sidx, const int *__restrict__ off,
+                const int *__restrict__ woff, const T *__restrict__ plike, T *__restrict__ V) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw_gather81[];
+  T *s_tile_pl = reinterpret_cast<T *>(s_raw_gather81);
+  int tile, pb, pe;
+  if (!tile_work(tp, off, woff, tile, pb, pe)) return;
+  const int ncell = tp.lx * LY * LZ;
+  const int n = g.n;
+  const int tzi = tile % tp.ntz, tyi = (tile / tp.ntz) % tp.nty, txi = tile / (tp.ntz * tp.nty);
+  const int ox = txi * tp.tx - 2, oy = tyi * tp.ty - 2, oz = tzi * tp.tz - 2;
+  for (int c = threadIdx.x; c < ncell; c += blockDim.x) {
+    const int cz = c % LZ, cy = (c / LZ) % LY, cx = c / (LZ * LY);
+    const int gx = (ox + cx + n) % n, gy = (oy + cy + n) % n, gz = (oz + cz + n) % n;
+    s_tile_pl[c] = plike[gz + (long long)n * (gy + (long long)n * gx)];
+  }
+  __syncthreads();
+  const T d = (T)g.d, d_h = (T)hp.d_h, h_inv = (T)hp.h_inv, norm = (T)hp.norm;
+  for (int s = pb + threadIdx.x; s < pe; s += blockDim.x) {
+    const T px = sx[s], py = sy[s], pz = sz[s];
+    const int ix = (int)home_cell(px, d), iy = (int)home_cell(py, d), iz = (int)home_cell(pz, d);
+    const T dpcx = px * h_inv - ((T)ix + T(0.5)) * d_h;
+    const T dpcy = py * h_inv - ((T)iy + T(0.5)) * d_h;
+    const T dpcz = pz * h_inv - ((T)iz + T(0.5)) * d_h;
+    const int hx = (ix % n) - ox, hy = (iy % n) - oy, hz = (iz % n) - oz;
+    T vx = T(0), vy = T(0), vz = T(0);
+    const bool home_ok = (unsigned)(hx - 2) < (unsigned)tp.tx && (unsigned)(hy - 2) < (unsigned)tp.ty &&
+                         (unsigned)(hz - 2) < (unsigned)tp.tz;  // always true; keeps LDS indexing safe
+    if (home_ok) {
+      T xh[5], yh[5], zh[5], X[5], Y[5], Z[5];
+#pragma unroll
+      for (int a = 0; a < 5; a++) {
+        xh[a] = dpcx - (T)(a - 2) * d_h;
+        yh[a] = dpcy - (T)(a - 2) * d_h;
+        zh[a] = dpcz - (T)(a - 2) * d_h;
+        X[a] = xh[a] * xh[a];
+        Y[a] = yh[a] * yh[a];
+        Z[a] = zh[a] * zh[a];
+      }
+      const T *corner = s_tile_pl + LZ * ((hy - 2) + LY * (hx - 2)) + (hz - 2);
+#pragma unroll
+      for (int a = 0; a < 5; a++) {
+#pragma unroll
+        for (int b = 0; b < 5; b++) {
+          const int zw = hull81_zw(a, b);  // folds after unrolling
+          if (zw < 0) continue;
+          const T r2ab = X[a] + Y[b];
+          if (r2ab > T(4)) continue;
+          const T *row = corner + LZ * (b + LY * a);
+#pragma unroll
+          for (int c = 0; c < 5; c++) {
+            if (c < 2 - zw || c > 2 + zw) continue;
+            const T q_sq = r2ab + Z[c];
+            if (q_sq <= T(4)) {
+              const T common = row[c] * sph_grad_partial<T>(q_sq, norm);
+              vx += common * xh[a];
+              vy += common * yh[b];
+              vz += common * zh[c];
+            }
+          }
+        }
       }
     }
     const T normalize = (T)hp.normalize;
