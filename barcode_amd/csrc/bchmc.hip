@@ -419,7 +419,9 @@ struct Pipe {
       if (h->c.mk == 3 && h->tiled) {
         const int grid = h->tp.ntiles + (int)(h->g.N / h->tp.chunk) + 1;  // upper bound on (tile, chunk) work items
         const int ncol = h->hull_exact ? h->hull_n : 0;
-        const int reorder = (h->tp.chunk == 2048 && !env_on("BCHMC_NO_SUBSORT")) ? 1 : 0;
+        // sub-cell ordering inside each work item: binary digits per axis (BCHMC_SUBSORT_BITS = 0 / 1 / 2)
+        const char *sb = std::getenv("BCHMC_SUBSORT_BITS");
+        const int reorder = (h->tp.chunk != 2048) ? 0 : (sb ? std::min(std::max(atoi(sb), 0), 2) : 2);
         if (h->std81)
           k_scatter_tile81<T, 12, 20><<<grid, 256, tile_lds(h, 0, sizeof(double)), h->stream>>>(
               h->g, sp, h->tp, reorder, R(h->sx), R(h->sy), R(h->sz), h->sidx, h->t_off, h->t_woff, R(h->rho));

@@ -191,24 +191,25 @@ __device__ __forceinline__ double sph_w(double q, double w_norm) {
   return w_norm * (1. / 4 * (t * t * t));
 }
 
-// W_4 (massFunctions.cc:366-384), branch-free; valid for 0 <= q <= 2.
+// W_4 (massFunctions.cc:366-384), branch-free, valid for 0 <= q <= 2, with the normalisation folded into the
+// coefficients (w = w_norm).
 template <typename T>
-__device__ __forceinline__ T sph_w_sel(T q, T w_norm) {
-  const T inner = r_fma(q * q, r_fma(T(0.75), q, T(-1.5)), T(1));  // 1 - 3/2 q^2 + 3/4 q^3
+__device__ __forceinline__ T sph_w_folded(T q, T w) {
+  const T inner = r_fma(q * q, r_fma(T(0.75) * w, q, T(-1.5) * w), w);  // w (1 - 3/2 q^2 + 3/4 q^3)
   const T t = T(2) - q;
-  const T outer = T(0.25) * (t * t * t);
-  return w_norm * ((q <= T(1)) ? inner : outer);
+  const T outer = (T(0.25) * w * t) * (t * t);
+  return (q <= T(1)) ? inner : outer;
 }
 
-// dW_4/dq / q in h units times `norm` (grad_SPH_kernel_3D_h_units, SPH_kernel.cpp:148-208), branch-free;
-// q_sq in (0, 4].
+// dW_4/dq / q in h units times `norm` (grad_SPH_kernel_3D_h_units, SPH_kernel.cpp:148-208), branch-free, folded
+// coefficients; q_sq in [0, 4]: q_sq + tiny instead of max(q_sq, tiny) (identical unless q_sq < 1e-264).
 template <typename T>
-__device__ __forceinline__ T sph_grad_partial(T q_sq, T norm) {
-  const T rq = fast_rsqrt(r_max(q_sq, tiny_pos<T>()));
+__device__ __forceinline__ T sph_grad_folded(T q_sq, T norm) {
+  const T rq = fast_rsqrt(q_sq + tiny_pos<T>());
   const T q = q_sq * rq;
-  const T inner = (T(2.25) * q - T(3)) * norm;
+  const T inner = r_fma(T(2.25) * norm, q, T(-3) * norm);
   const T qm2 = q - T(2);
-  const T outer = (T(-0.75) * qm2 * qm2 * norm) * rq;
+  const T outer = ((qm2 * qm2) * (T(-0.75) * norm)) * rq;
   return (q_sq > T(1)) ? outer : inner;
 }
 
@@ -934,10 +935,38 @@ __device__ __forceinline__ int tile_of(const TilePar &tp, int n, long long ix, l
   return (cz / tp.tz) + tp.ntz * ((cy / tp.ty) + tp.nty * (cx / tp.tx));
 }
 
-// Home cell of a position: (ULONG)(xp/d1), massFunctions.cc:434-436 (same expression in every kernel).
+// Home cell of a position: (ULONG)(xp/d1), massFunctions.cc:434-436.
 template <typename T>
 __device__ __forceinline__ long long home_cell(T x, T d) {
   return (long long)(x / d);
+}
+
+// The same cell for the sorted path (positions there are in [0, L], so the result is in [0, n]) without the IEEE
+// divide: x * (1/d) is within a few ulp of x / d, so truncating it gives the reference's cell unless the quotient
+// is that close to an integer; only then is the division itself evaluated.  Deterministic in (x, d): the binning
+// pass and the scatter/gather passes always agree.
+template <typename T> struct HomeCell {
+  T d, inv_d, thr;
+  int n;
+};
+template <typename T>
+__device__ __forceinline__ HomeCell<T> make_home(const Geo &g) {
+  HomeCell<T> hc;
+  hc.d = (T)g.d;
+  hc.inv_d = T(1) / hc.d;
+  hc.thr = (T)g.n * (sizeof(T) == 8 ? T(1e-15) : T(5e-7));  // >= 4 ulp of the largest quotient
+  hc.n = g.n;
+  return hc;
+}
+template <typename T>
+__device__ __forceinline__ int home_cell_i(const HomeCell<T> &hc, T x) {
+  const T f = x * hc.inv_d;
+  if (__builtin_expect(fabs(f - rint(f)) < hc.thr, 0)) return (int)(x / hc.d);
+  return (int)f;
+}
+__device__ __forceinline__ int wrap_cell(int c, int n) { return c >= n ? c - n : c; }
+__device__ __forceinline__ int tile_of_wrapped(const TilePar &tp, int cx, int cy, int cz) {
+  return (cz / tp.tz) + tp.ntz * ((cy / tp.ty) + tp.nty * (cx / tp.tx));
 }
 
 // Workgroup -> particles.  When 16 divides n a workgroup takes a 4 x 4 x 16 brick of the Lagrangian lattice
@@ -984,8 +1013,9 @@ k_bin(Geo g, PosPar pp, SphPar sp, TilePar tp, const T *__restrict__ psi, int *_
     T x, y, z;
     particle_pos<T>(pp, i, j, k, psi[p], psi[p + g.N], psi[p + 2 * g.N], x, y, z);
     if (pos_ok(g, x, y, z)) {
-      const T d = (T)g.d;
-      t = tile_of(tp, g.n, home_cell(x, d), home_cell(y, d), home_cell(z, d));
+      const HomeCell<T> hc = make_home<T>(g);
+      t = tile_of_wrapped(tp, wrap_cell(home_cell_i(hc, x), g.n), wrap_cell(home_cell_i(hc, y), g.n),
+                          wrap_cell(home_cell_i(hc, z), g.n));
       flag = in_domain(g, sp, x, y, z) ? 0 : kSortFlagNoScatter;
       slot = (int)(((unsigned)t * 2654435761u) >> 23) & (kSlots - 1);
       for (;;) {
@@ -1097,18 +1127,21 @@ __device__ __forceinline__ bool tile_work(const TilePar &tp, const int *__restri
   return tile >= 0;
 }
 
-// Order one work item's records by the octant of the particle's sub-cell offset (in place; the gather reads the
-// same order).  The 64 lanes of a wave then share the set of stencil cells that can pass the `r/h <= 2` test
-// (51 instead of 81 on average), and a wave pays for every candidate ANY of its lanes needs.  Pure reordering:
-// results do not depend on it.  Requires chunk == 256 * 8 and blockDim.x == 256.
+// Order one work item's records by the sub-cell position of the particle (in place; the gather reads the same
+// order): `bits` binary digits of the fractional cell coordinate per axis, octant digits most significant.  The 64
+// lanes of a wave then share most of the stencil cells that can pass the `r/h <= 2` test, and a wave pays for
+// every candidate ANY of its lanes needs (81 unsorted, ~51 with octants, fewer with 4 x 4 x 4 bins).  Pure
+// reordering: results do not depend on it.  Requires chunk == 256 * 8 and blockDim.x == 256.
 template <typename T>
-__device__ __forceinline__ void subsort_octants(int pb, int pe, T d, T *sx, T *sy, T *sz, int *sidx) {
+__device__ __forceinline__ void subsort_subcell(int bits, int pb, int pe, T inv_d, T *sx, T *sy, T *sz, int *sidx) {
   constexpr int kPer = 8;  // tp.chunk == 256 * kPer
-  __shared__ int hist[8], base[8];
-  if (threadIdx.x < 8) hist[threadIdx.x] = 0;
+  __shared__ int hist[64], base[64];
+  const int nb = 1 << (3 * bits);
+  if (threadIdx.x < 64) hist[threadIdx.x] = 0;
   __syncthreads();
   T rx[kPer], ry[kPer], rz[kPer];
   int id[kPer], key[kPer], rank[kPer];
+  const T scale = (T)(1 << bits);
 #pragma unroll
   for (int m = 0; m < kPer; m++) {
     const int s = pb + (int)threadIdx.x + 256 * m;
@@ -1117,16 +1150,20 @@ __device__ __forceinline__ void subsort_octants(int pb, int pe, T d, T *sx, T *s
       ry[m] = sy[s];
       rz[m] = sz[s];
       id[m] = sidx[s];
-      const T fx = rx[m] / d, fy = ry[m] / d, fz = rz[m] / d;
-      key[m] = (((fx - r_floor(fx)) >= T(0.5)) << 2) | (((fy - r_floor(fy)) >= T(0.5)) << 1) |
-               ((fz - r_floor(fz)) >= T(0.5));
-      rank[m] = atomicAdd(&hist[key[m]], 1);
+      const T fx = rx[m] * inv_d, fy = ry[m] * inv_d, fz = rz[m] * inv_d;  // ordering only
+      const int ux = min((int)((fx - r_floor(fx)) * scale), (1 << bits) - 1);
+      const int uy = min((int)((fy - r_floor(fy)) * scale), (1 << bits) - 1);
+      const int uz = min((int)((fz - r_floor(fz)) * scale), (1 << bits) - 1);
+      int kk = 0;
+      for (int b = bits - 1; b >= 0; b--) kk = (kk << 3) | (((ux >> b) & 1) << 2) | (((uy >> b) & 1) << 1) | ((uz >> b) & 1);
+      key[m] = kk;
+      rank[m] = atomicAdd(&hist[kk], 1);
     }
   }
   __syncthreads();
   if (threadIdx.x == 0) {
     int acc = 0;
-    for (int b = 0; b < 8; b++) {
+    for (int b = 0; b < nb; b++) {
       base[b] = acc;
       acc += hist[b];
     }
@@ -1160,7 +1197,8 @@ k_scatter_tile(Geo g, SphPar sp, TilePar tp, const int4 *__restrict__ cols, int 
   for (int m = threadIdx.x; m < ncol; m += blockDim.x) s_cols[m] = cols[m];
   for (int c = threadIdx.x; c < ncell; c += blockDim.x) s_tile_acc[c] = 0.;
   const T d = (T)g.d;
-  if (reorder) subsort_octants<T>(pb, pe, d, sx, sy, sz, sidx);
+  const HomeCell<T> hc = make_home<T>(g);
+  if (reorder) subsort_subcell<T>(reorder, pb, pe, hc.inv_d, sx, sy, sz, sidx);
   __syncthreads();
   const int tzi = tile % tp.ntz, tyi = (tile / tp.ntz) % tp.nty, txi = tile / (tp.ntz * tp.nty);
   const int ox = txi * tp.tx - tp.R, oy = tyi * tp.ty - tp.R, oz = tzi * tp.tz - tp.R;  // global cell of LDS (0,0,0)
@@ -1169,9 +1207,9 @@ k_scatter_tile(Geo g, SphPar sp, TilePar tp, const int4 *__restrict__ cols, int 
   for (int s = pb + threadIdx.x; s < pe; s += blockDim.x) {
     if (sidx[s] & kSortFlagNoScatter) continue;
     const T x = sx[s], y = sy[s], z = sz[s];
-    const long long ix = home_cell(x, d), iy = home_cell(y, d), iz = home_cell(z, d);
+    const int ix = home_cell_i(hc, x), iy = home_cell_i(hc, y), iz = home_cell_i(hc, z);
     const T ccx = ((T)ix + T(0.5)) * d, ccy = ((T)iy + T(0.5)) * d, ccz = ((T)iz + T(0.5)) * d;
-    const int hx = (int)(ix % n) - ox, hy = (int)(iy % n) - oy, hz = (int)(iz % n) - oz;  // home cell in LDS coords
+    const int hx = wrap_cell(ix, n) - ox, hy = wrap_cell(iy, n) - oy, hz = wrap_cell(iz, n) - oz;  // home cell in LDS coords
     if ((unsigned)(hx - tp.R) >= (unsigned)tp.tx || (unsigned)(hy - tp.R) >= (unsigned)tp.ty ||
         (unsigned)(hz - tp.R) >= (unsigned)tp.tz)
       continue;  // cannot happen (binning and this kernel see the same stored position); keeps LDS indexing safe
@@ -1188,8 +1226,8 @@ k_scatter_tile(Geo g, SphPar sp, TilePar tp, const int4 *__restrict__ cols, int 
           const T dz = z - (ccz + (T)i3 * d);
           const T r2 = r2ab + dz * dz;
           if (r2 <= r2_lim) {
-            const T q = (r2 * fast_rsqrt(r_max(r2, tiny_pos<T>()))) * h_inv;
-            if (q <= T(2)) atomic_add_r(row + i3, (double)sph_w_sel<T>(q, w_norm));
+            const T q = (r2 * fast_rsqrt(r2 + tiny_pos<T>())) * h_inv;
+            if (q <= T(2)) atomic_add_r(row + i3, (double)sph_w_folded<T>(q, w_norm));
           }
         }
       }
@@ -1207,8 +1245,8 @@ k_scatter_tile(Geo g, SphPar sp, TilePar tp, const int4 *__restrict__ cols, int 
             const T dz = z - (ccz + (T)i3 * d);
             const T r2 = r2ab + dz * dz;
             if (r2 > r2_lim) continue;
-            const T q = (r2 * fast_rsqrt(r_max(r2, tiny_pos<T>()))) * h_inv;
-            if (q <= T(2)) atomic_add_r(row + i3, (double)sph_w_sel<T>(q, w_norm));
+            const T q = (r2 * fast_rsqrt(r2 + tiny_pos<T>())) * h_inv;
+            if (q <= T(2)) atomic_add_r(row + i3, (double)sph_w_folded<T>(q, w_norm));
           }
         }
       }
@@ -1247,14 +1285,15 @@ k_gather_tile(Geo g, HullPar hp, TilePar tp, int rsd, const T *__restrict__ sx, 
     s_tile_pl[c] = plike[gz + (long long)n * (gy + (long long)n * gx)];
   }
   __syncthreads();
-  const T d = (T)g.d, d_h = (T)hp.d_h, h_inv = (T)hp.h_inv, norm = (T)hp.norm;
+  const T d_h = (T)hp.d_h, h_inv = (T)hp.h_inv, norm = (T)hp.norm;
+  const HomeCell<T> hc = make_home<T>(g);
   for (int s = pb + threadIdx.x; s < pe; s += blockDim.x) {
     const T px = sx[s], py = sy[s], pz = sz[s];
-    const int ix = (int)home_cell(px, d), iy = (int)home_cell(py, d), iz = (int)home_cell(pz, d);
+    const int ix = home_cell_i(hc, px), iy = home_cell_i(hc, py), iz = home_cell_i(hc, pz);
     const T dpcx = px * h_inv - ((T)ix + T(0.5)) * d_h;
     const T dpcy = py * h_inv - ((T)iy + T(0.5)) * d_h;
     const T dpcz = pz * h_inv - ((T)iz + T(0.5)) * d_h;
-    const int hx = (ix % n) - ox, hy = (iy % n) - oy, hz = (iz % n) - oz;
+    const int hx = wrap_cell(ix, n) - ox, hy = wrap_cell(iy, n) - oy, hz = wrap_cell(iz, n) - oz;
     T vx = T(0), vy = T(0), vz = T(0);
     const bool home_ok = (unsigned)(hx - tp.R) < (unsigned)tp.tx && (unsigned)(hy - tp.R) < (unsigned)tp.ty &&
                          (unsigned)(hz - tp.R) < (unsigned)tp.tz;  // always true; keeps LDS indexing safe
@@ -1269,7 +1308,7 @@ k_gather_tile(Geo g, HullPar hp, TilePar tp, int rsd, const T *__restrict__ sx, 
       for (int i3 = c.z; i3 <= c.w; ++i3) {
         const T q_sq = r2ab + zh * zh;
         if (q_sq <= T(4)) {
-          const T common = row[i3] * sph_grad_partial<T>(q_sq, norm);
+          const T common = row[i3] * sph_grad_folded<T>(q_sq, norm);
           vx += common * xh;
           vy += common * yh;
           vz += common * zh;
@@ -1314,7 +1353,8 @@ k_scatter_tile81(Geo g, SphPar sp, TilePar tp, int reorder, T *sx, T *sy, T *sz,
   const int ncell = tp.lx * LY * LZ;
   for (int c = threadIdx.x; c < ncell; c += blockDim.x) s_tile_acc[c] = 0.;
   const T d = (T)g.d;
-  if (reorder) subsort_octants<T>(pb, pe, d, sx, sy, sz, sidx);
+  const HomeCell<T> hc = make_home<T>(g);
+  if (reorder) subsort_subcell<T>(reorder, pb, pe, hc.inv_d, sx, sy, sz, sidx);
   __syncthreads();
   const int tzi = tile % tp.ntz, tyi = (tile / tp.ntz) % tp.nty, txi = tile / (tp.ntz * tp.nty);
   const int ox = txi * tp.tx - 2, oy = tyi * tp.ty - 2, oz = tzi * tp.tz - 2;  // global cell of LDS (0,0,0)
@@ -1323,9 +1363,9 @@ k_scatter_tile81(Geo g, SphPar sp, TilePar tp, int reorder, T *sx, T *sy, T *sz,
   for (int s = pb + threadIdx.x; s < pe; s += blockDim.x) {
     if (sidx[s] & kSortFlagNoScatter) continue;
     const T x = sx[s], y = sy[s], z = sz[s];
-    const long long ix = home_cell(x, d), iy = home_cell(y, d), iz = home_cell(z, d);
+    const int ix = home_cell_i(hc, x), iy = home_cell_i(hc, y), iz = home_cell_i(hc, z);
     const T ccx = ((T)ix + T(0.5)) * d, ccy = ((T)iy + T(0.5)) * d, ccz = ((T)iz + T(0.5)) * d;
-    const int hx = (int)(ix % n) - ox, hy = (int)(iy % n) - oy, hz = (int)(iz % n) - oz;  // home cell in LDS coords
+    const int hx = wrap_cell(ix, n) - ox, hy = wrap_cell(iy, n) - oy, hz = wrap_cell(iz, n) - oz;  // home cell in LDS coords
     if ((unsigned)(hx - 2) >= (unsigned)tp.tx || (unsigned)(hy - 2) >= (unsigned)tp.ty ||
         (unsigned)(hz - 2) >= (unsigned)tp.tz)
       continue;  // cannot happen (binning and this kernel see the same stored position); keeps LDS indexing safe
@@ -1352,8 +1392,8 @@ k_scatter_tile81(Geo g, SphPar sp, TilePar tp, int reorder, T *sx, T *sy, T *sz,
           if (c < 2 - zw || c > 2 + zw) continue;
           const T r2 = r2ab + Z[c];
           if (r2 <= r2_lim) {
-            const T q = (r2 * fast_rsqrt(r_max(r2, tiny_pos<T>()))) * h_inv;
-            if (q <= T(2)) atomic_add_r(row + c, (double)sph_w_sel<T>(q, w_norm));
+            const T q = (r2 * fast_rsqrt(r2 + tiny_pos<T>())) * h_inv;
+            if (q <= T(2)) atomic_add_r(row + c, (double)sph_w_folded<T>(q, w_norm));
           }
         }
       }
@@ -1389,14 +1429,15 @@ k_gather_tile81(Geo g, HullPar hp, TilePar tp, int rsd, const T *__restrict__ sx
     s_tile_pl[c] = plike[gz + (long long)n * (gy + (long long)n * gx)];
   }
   __syncthreads();
-  const T d = (T)g.d, d_h = (T)hp.d_h, h_inv = (T)hp.h_inv, norm = (T)hp.norm;
+  const T d_h = (T)hp.d_h, h_inv = (T)hp.h_inv, norm = (T)hp.norm;
+  const HomeCell<T> hc = make_home<T>(g);
   for (int s = pb + threadIdx.x; s < pe; s += blockDim.x) {
     const T px = sx[s], py = sy[s], pz = sz[s];
-    const int ix = (int)home_cell(px, d), iy = (int)home_cell(py, d), iz = (int)home_cell(pz, d);
+    const int ix = home_cell_i(hc, px), iy = home_cell_i(hc, py), iz = home_cell_i(hc, pz);
     const T dpcx = px * h_inv - ((T)ix + T(0.5)) * d_h;
     const T dpcy = py * h_inv - ((T)iy + T(0.5)) * d_h;
     const T dpcz = pz * h_inv - ((T)iz + T(0.5)) * d_h;
-    const int hx = (ix % n) - ox, hy = (iy % n) - oy, hz = (iz % n) - oz;
+    const int hx = wrap_cell(ix, n) - ox, hy = wrap_cell(iy, n) - oy, hz = wrap_cell(iz, n) - oz;
     T vx = T(0), vy = T(0), vz = T(0);
     const bool home_ok = (unsigned)(hx - 2) < (unsigned)tp.tx && (unsigned)(hy - 2) < (unsigned)tp.ty &&
                          (unsigned)(hz - 2) < (unsigned)tp.tz;  // always true; keeps LDS indexing safe
@@ -1426,7 +1467,7 @@ k_gather_tile81(Geo g, HullPar hp, TilePar tp, int rsd, const T *__restrict__ sx
             if (c < 2 - zw || c > 2 + zw) continue;
             const T q_sq = r2ab + Z[c];
             if (q_sq <= T(4)) {
-              const T common = row[c] * sph_grad_partial<T>(q_sq, norm);
+              const T common = row[c] * sph_grad_folded<T>(q_sq, norm);
               vx += common * xh[a];
               vy += common * yh[b];
               vz += common * zh[c];
