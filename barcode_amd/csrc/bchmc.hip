@@ -59,6 +59,7 @@ struct bchmc_handle {
 
   // state and scratch (T / C2<T>)
   void *qk = nullptr, *pk = nullptr, *gk = nullptr;  // Nhp complex each
+  void *qk2 = nullptr, *pk2 = nullptr;               // ping-pong partners of (qk, pk) for the fused step boundary
   void *Ck = nullptr;                                // 3 Nhp: Psi^ / V^
   void *tC = nullptr;                                // Nhp scratch
   void *psi = nullptr;                               // 3 N: displacement components
@@ -668,9 +669,11 @@ struct Pipe {
 
     const bool fused_za = (h->c.likelihood != 3);
     const double *wM = h->mass_fs ? h->wM : nullptr;
+    const double c_za = -h->c.D1 * h->c.deltaQ_factor / (double)h->g.N;
+    const double guard_limit = 1e50 * (double)h->g.N;
+    if (fused_za && !h->mass_rs && !env_on("BCHMC_NO_FUSE")) return trajectory_fused(h, eps, neps, tap, a, wM, c_za);
     for (uint64_t s = 0; s < neps; s++) {
-      StepCtl ctl{h->stop, h->steps_done, s > 0 ? h->guard + (s - 1) : nullptr, 1e50 * (double)h->g.N, s};
-      const double c_za = -h->c.D1 * h->c.deltaQ_factor / (double)h->g.N;
+      StepCtl ctl{h->stop, h->steps_done, s > 0 ? h->guard + (s - 1) : nullptr, guard_limit, s};
       if (!h->mass_rs) {
         ProfScope ps(h, BCHMC_K_KSPACE_DRIFT_ZA);
         k_kick_drift_za<T, true><<<nblk_stride(h->g.Nhp), 256, 0, h->stream>>>(h->g, C(h->qk), C(h->pk), C(h->gk), wM,
@@ -694,6 +697,58 @@ struct Pipe {
       CHK(force_sources(h, fused_za, &like_mode, &b));
       if (tap && tap->like_f && s + 1 == neps) CHK(tap_loglike(h, tap->like_f));
       CHK(launch_assemble<true>(h, a, b, like_mode, 0.5 * eps, h->guard + s));
+    }
+    return BCHMC_OK;
+  }
+
+  // The same trajectory with every interior "second half kick | first half kick + drift + Zel'dovich" pair done by
+  // one kernel (k_step_boundary) on ping-pong state buffers.  Used for k-space masses and forward-model likelihoods.
+  static int trajectory_fused(bchmc_handle *h, double eps, uint64_t neps, const Tap *tap, double a, const double *wM,
+                              double c_za) {
+    const double guard_limit = 1e50 * (double)h->g.N;
+    if (!h->qk2) {
+      CHK(dev_alloc_bytes(h, &h->qk2, 2 * (size_t)h->g.Nhp * sizeof(T)));
+      CHK(dev_alloc_bytes(h, &h->pk2, 2 * (size_t)h->g.Nhp * sizeof(T)));
+    }
+    void *const q0 = h->qk, *const p0 = h->pk, *const q1 = h->qk2, *const p1 = h->pk2;
+    int like_mode = 2;
+    double b = 0.;
+    int cur = 0;  // boundary j reads pair j % 2
+    {
+      StepCtl ctl{h->stop, h->steps_done, nullptr, guard_limit, 0};
+      ProfScope ps(h, BCHMC_K_KSPACE_DRIFT_ZA);
+      k_kick_drift_za<T, true><<<nblk_stride(h->g.Nhp), 256, 0, h->stream>>>(h->g, C(q0), C(p0), C(h->gk), wM, nullptr,
+                                                                           C(h->Ck), 0.5 * eps, eps, c_za, ctl);
+      HIPCHK(hipGetLastError());
+    }
+    for (uint64_t s = 0; s < neps; s++) {
+      CHK(force_sources(h, true, &like_mode, &b));
+      const bool last = (s + 1 == neps);
+      if (tap && tap->like_f && last) CHK(tap_loglike(h, tap->like_f));
+      StepCtl ctl{h->stop, h->steps_done, s > 0 ? h->guard + (s - 1) : nullptr, guard_limit, s};
+      void *qi = cur ? q1 : q0, *pi = cur ? p1 : p0, *qo = cur ? q0 : q1, *po = cur ? p0 : p1;
+      ProfScope ps(h, BCHMC_K_KSPACE_FORCE_KICK);
+      if (last) {
+        k_step_boundary<T, true><<<nblk_stride(h->g.Nhp), 256, 0, h->stream>>>(
+            h->g, C(h->Ck), C(qi), C(pi), C(qi), C(pi), C(h->gk), h->wS, wM, a, b, like_mode, 0.5 * eps, eps, c_za,
+            h->guard + s, ctl);
+      } else {
+        k_step_boundary<T, false><<<nblk_stride(h->g.Nhp), 256, 0, h->stream>>>(
+            h->g, C(h->Ck), C(qi), C(pi), C(qo), C(po), C(h->gk), h->wS, wM, a, b, like_mode, 0.5 * eps, eps, c_za,
+            h->guard + s, ctl);
+        cur ^= 1;
+      }
+      HIPCHK(hipGetLastError());
+    }
+    {
+      ProfScope ps(h, BCHMC_K_OTHER);
+      k_rollback<T><<<nblk_stride(h->g.Nhp), 256, 0, h->stream>>>(h->g.Nhp, h->stop, h->steps_done, C(q0), C(p0), C(q1),
+                                                                 C(p1), C(cur ? q1 : q0), C(cur ? p1 : p0));
+      HIPCHK(hipGetLastError());
+    }
+    if (cur) {
+      std::swap(h->qk, h->qk2);
+      std::swap(h->pk, h->pk2);
     }
     return BCHMC_OK;
   }
@@ -1189,7 +1244,7 @@ void bchmc_destroy(bchmc_handle *h) {
   if (h->info) rocfft_execution_info_destroy(h->info);
   void *ptrs[] = {h->work,  h->wS,       h->wM,    h->qk,    h->pk,   h->gk,     h->Ck,         h->tC,   h->psi,
                   h->V,     h->rho,      h->plike, h->ioq,   h->iop,  h->gprior, h->glike,      h->conv, h->convF,
-                  h->dstage, h->cq, h->cp, h->part6, h->rho_part, h->partA, h->guard, h->stop, h->steps_done, h->hull,  h->t_cnt, h->t_off,
+                  h->dstage, h->cq, h->cp, h->qk2, h->pk2, h->part6, h->rho_part, h->partA, h->guard, h->stop, h->steps_done, h->hull,  h->t_cnt, h->t_off,
                   h->t_woff, h->t_rank,  h->sx,    h->sy,    h->sz,   h->sidx};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);

@@ -479,6 +479,37 @@ k_gather_sph(Geo g, PosPar pp, HullPar hp, const T *__restrict__ psi, const T *_
 // like_mode 0: h^ from the three V^ (calc_h 0/2/3); 1: h^ = Ck[0] as is (calc_h 1, GRF); 2: no likelihood term.
 // The guard slot receives sum_k hw_k Re p^_k = N * p[0] (HMC.cc:360).
 // ------------------------------------------------------------------------------------------------------
+// g^ of one k-space element (shared by k_assemble and the fused step kernel)
+template <typename T>
+__device__ __forceinline__ double2 assemble_g(const Geo &g, const C2<T> *__restrict__ Ck, const double2 q,
+                                              const double *__restrict__ wS, long long idx, int k, double a, double b,
+                                              int like_mode) {
+  double2 hk = make_double2(0., 0.);
+  if (like_mode == 0) {
+    const long long ij = idx / g.nhp;
+    const int j = (int)(ij % g.n), i = (int)(ij / g.n);
+    const bool nyq = (i == g.n / 2) || (j == g.n / 2) || (k == g.n / 2);
+    const double kx = kval(i, g.n, g.kfac), ky = kval(j, g.n, g.kfac), kz = kval(k, g.n, g.kfac);
+    const double kmod = kx * kx + ky * ky + kz * kz;
+    if (kmod > 0 && !nyq) {
+      const double f = 1 / kmod;
+      const double2 vx = ld2<T>(Ck, idx), vy = ld2<T>(Ck, idx + g.Nhp), vz = ld2<T>(Ck, idx + 2 * g.Nhp);
+      const double fx = kx * f, fy = ky * f, fz = kz * f;
+      hk.x = fx * vx.y + fy * vy.y + fz * vz.y;
+      hk.y = -(fx * vx.x) - fy * vy.x - fz * vz.x;
+    }
+  } else if (like_mode == 1) {
+    hk = ld2<T>(Ck, idx);
+  }
+  double2 gg = make_double2(b * hk.x, b * hk.y);
+  if (a != 0.) {
+    const double w = a * wS[idx];
+    gg.x += w * q.x;
+    gg.y += w * q.y;
+  }
+  return gg;
+}
+
 template <typename T, bool KICK>
 __global__ void __launch_bounds__(256)
 k_assemble(Geo g, const C2<T> *__restrict__ Ck, const C2<T> *__restrict__ qk, const double *__restrict__ wS,
@@ -490,30 +521,8 @@ k_assemble(Geo g, const C2<T> *__restrict__ Ck, const C2<T> *__restrict__ qk, co
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < g.Nhp;
        idx += (long long)gridDim.x * blockDim.x) {
     const int k = (int)(idx % g.nhp);
-    double2 hk = make_double2(0., 0.);
-    if (like_mode == 0) {
-      const long long ij = idx / g.nhp;
-      const int j = (int)(ij % g.n), i = (int)(ij / g.n);
-      const bool nyq = (i == g.n / 2) || (j == g.n / 2) || (k == g.n / 2);
-      const double kx = kval(i, g.n, g.kfac), ky = kval(j, g.n, g.kfac), kz = kval(k, g.n, g.kfac);
-      const double kmod = kx * kx + ky * ky + kz * kz;
-      if (kmod > 0 && !nyq) {
-        const double f = 1 / kmod;
-        const double2 vx = ld2<T>(Ck, idx), vy = ld2<T>(Ck, idx + g.Nhp), vz = ld2<T>(Ck, idx + 2 * g.Nhp);
-        const double fx = kx * f, fy = ky * f, fz = kz * f;
-        hk.x = fx * vx.y + fy * vy.y + fz * vz.y;
-        hk.y = -(fx * vx.x) - fy * vy.x - fz * vz.x;
-      }
-    } else if (like_mode == 1) {
-      hk = ld2<T>(Ck, idx);
-    }
-    double2 gg = make_double2(b * hk.x, b * hk.y);
-    if (a != 0.) {
-      const double2 q = ld2<T>(qk, idx);
-      const double w = a * wS[idx];
-      gg.x += w * q.x;
-      gg.y += w * q.y;
-    }
+    const double2 q = (a != 0.) ? ld2<T>(qk, idx) : make_double2(0., 0.);
+    const double2 gg = assemble_g<T>(g, Ck, q, wS, idx, k, a, b, like_mode);
     st2<T>(gk, idx, gg.x, gg.y);
     if (KICK) {
       double2 p = ld2<T>(pk, idx);
@@ -527,6 +536,103 @@ k_assemble(Geo g, const C2<T> *__restrict__ Ck, const C2<T> *__restrict__ qk, co
   if (KICK) {
     gsum = block_sum(gsum, red);
     if (threadIdx.x == 0) atomic_add_r(guard_slot, gsum);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Fused interior step boundary: the k_assemble<KICK> of step s followed by the k_kick_drift_za of step s + 1 in
+// one pass (HMC.cc:351-352, then 290-291, 300-337 of the next iteration):
+//   g^ = a wS q^ + b h^;  p_end = p - (eps/2) g^  [guard sum of step s];  p' = p_end - (eps/2) g^;
+//   q' = q + eps wM p';  Psi^' from q'.
+// (q', p') go to the other buffer of a ping-pong pair: if the guard of step s turns out to have tripped, the next
+// kernel of this kind stops the trajectory and k_rollback rebuilds the end-of-step-s state from the two buffers.
+// V^ is read from and Psi^' written to the same Ck elements by the same thread.
+// ------------------------------------------------------------------------------------------------------
+// LAST = true is the boundary after the final step: only the half kick (p_out = p_end, which may alias p_in), g^
+// stored to gk (hd->gradpsi), q untouched.
+template <typename T, bool LAST>
+__global__ void __launch_bounds__(256)
+k_step_boundary(Geo g, C2<T> *Ck, const C2<T> *q_in, const C2<T> *p_in, C2<T> *q_out, C2<T> *p_out,
+                C2<T> *__restrict__ gk, const double *__restrict__ wS, const double *__restrict__ wM, double a,
+                double b, int like_mode, double half_eps, double eps, double c_za, double *guard_slot, StepCtl ctl) {
+  __shared__ double red[4];
+  if (*ctl.stop) return;
+  if (ctl.guard_prev && fabs(*ctl.guard_prev) > ctl.guard_limit) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      *ctl.steps_done = ctl.step_index;
+      __threadfence();
+      *ctl.stop = 1;
+    }
+    return;  // NB: *stop is only read by LATER kernels, every thread of this one takes this branch
+  }
+  double gsum = 0.;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < g.Nhp;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int k = (int)(idx % g.nhp);
+    double2 q = ld2<T>(q_in, idx);
+    const double2 gg = assemble_g<T>(g, Ck, q, wS, idx, k, a, b, like_mode);
+    double2 p = ld2<T>(p_in, idx);
+    // The unfused kernels store p_end and g^ (rounded to T) between the two half kicks: same roundings here, so
+    // that fused and unfused trajectories are the same numbers (bit-identical for T = double).
+    C2<T> pe, gs;
+    pe.x = (T)(p.x - half_eps * gg.x);
+    pe.y = (T)(p.y - half_eps * gg.y);
+    gs.x = (T)gg.x;
+    gs.y = (T)gg.y;
+    const double hw = (k == 0 || ((g.n & 1) == 0 && k == g.n / 2)) ? 1. : 2.;
+    if (k < g.nh) gsum += hw * (double)pe.x;
+    if (LAST) {
+      p_out[idx] = pe;
+      gk[idx] = gs;
+      continue;
+    }
+    p.x = (double)pe.x - half_eps * (double)gs.x;
+    p.y = (double)pe.y - half_eps * (double)gs.y;
+    st2<T>(p_out, idx, p.x, p.y);
+    if (wM) {
+      const double w = wM[idx];
+      q.x += eps * (w * p.x);
+      q.y += eps * (w * p.y);
+    }
+    st2<T>(q_out, idx, q.x, q.y);
+    const long long ij = idx / g.nhp;
+    const int j = (int)(ij % g.n), i = (int)(ij / g.n);
+    const double kx = kval(i, g.n, g.kfac), ky = kval(j, g.n, g.kfac), kz = kval(k, g.n, g.kfac);
+    const double ksq = kx * kx + ky * ky + kz * kz;
+    double2 ox = make_double2(0., 0.), oy = ox, oz = ox;
+    const bool nyq = (i == g.n / 2) || (j == g.n / 2) || (k == g.n / 2);
+    if (ksq > 1.e-14 && !nyq) {
+      const double fac = 1. / ksq;
+      const double pr = c_za * q.x, pi = c_za * q.y;
+      const double fx = fac * kx, fy = fac * ky, fz = fac * kz;
+      ox = make_double2(fx * pi, fx * -pr);
+      oy = make_double2(fy * pi, fy * -pr);
+      oz = make_double2(fz * pi, fz * -pr);
+    }
+    st2<T>(Ck, idx, ox.x, ox.y);
+    st2<T>(Ck, idx + g.Nhp, oy.x, oy.y);
+    st2<T>(Ck, idx + 2 * g.Nhp, oz.x, oz.y);
+  }
+  gsum = block_sum(gsum, red);
+  if (threadIdx.x == 0) atomic_add_r(guard_slot, gsum);
+}
+
+// After a trajectory of fused steps: if the guard stopped it at step s (= *steps_done, s >= 1), the state the
+// reference would return is (q_s, p_s_end) = (q of the buffer step-boundary s - 1 read, mean of the momenta it
+// read and wrote: p_read - (eps/2) g and p_written + (eps/2) g are the same number).  buf[i] are the ping-pong
+// pairs; boundary j reads pair j % 2; the result goes to (q_dst, p_dst), which may alias either pair.
+template <typename T>
+__global__ void k_rollback(long long n, const int *__restrict__ stop, const unsigned long long *__restrict__ steps_done,
+                           const C2<T> *q0, const C2<T> *p0, const C2<T> *q1, const C2<T> *p1, C2<T> *q_dst,
+                           C2<T> *p_dst) {
+  if (!*stop) return;
+  const unsigned long long s = *steps_done;  // boundary s detected the trip; boundary s - 1 wrote the overshoot
+  const bool read_is_0 = ((s - 1) & 1) == 0;
+  const C2<T> *qr = read_is_0 ? q0 : q1, *pr = read_is_0 ? p0 : p1, *pw = read_is_0 ? p1 : p0;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const double2 a = ld2<T>(pr, i), b = ld2<T>(pw, i), q = ld2<T>(qr, i);
+    st2<T>(p_dst, i, 0.5 * a.x + 0.5 * b.x, 0.5 * a.y + 0.5 * b.y);
+    st2<T>(q_dst, i, q.x, q.y);
   }
 }
 

@@ -151,6 +151,35 @@ def test_runaway_guard_matches_reference_semantics():
     e.close()
 
 
+@pytest.mark.parametrize("neps", [1, 2, 5, 6])
+def test_fused_step_boundary_is_the_unfused_trajectory(monkeypatch, neps):
+    """k_step_boundary (second half kick | first half kick + drift + Zel'dovich in one pass, ping-pong buffers) is the
+    same arithmetic as the separate k_assemble / k_kick_drift_za kernels (BCHMC_NO_FUSE=1): trajectories agree to the
+    order-of-summation noise of the scatter's float atomics, for odd and even numbers of buffer swaps, including a
+    trajectory stopped by the runaway guard."""
+    c = Case(Nx=16, likelihood=1, rsd_model=1)
+    p_bad = c.p0.copy().ravel()
+    p_bad[0] = 1e60
+    out = []
+    for nofuse in ("0", "1"):
+        monkeypatch.setenv("BCHMC_NO_FUSE", nofuse)
+        e = c.engine()
+        q1, p1, done = e.leapfrog(c.q0, c.p0, c.eps, neps)
+        qb, pb, doneb = e.leapfrog(c.q0, p_bad, 1e-6, neps + 3)
+        q2, p2, done2 = e.leapfrog(q1, p1, c.eps, neps)  # state buffers were swapped an odd/even number of times
+        out.append((q1, p1, done, qb, pb, doneb, q2, p2, done2))
+        e.close()
+    f, u = out
+    assert f[2] == u[2] == neps and f[8] == u[8] == neps and f[5] == u[5] == 1
+    noise = 1e-13
+    assert rel_l2(f[0], u[0]) < noise and rel_l2(f[1], u[1]) < noise
+    assert rel_l2(f[6], u[6]) < noise and rel_l2(f[7], u[7]) < noise
+    # stopped trajectory: rolled back to the end of the step that tripped the guard
+    assert rel_l2(f[3], u[3]) < noise and rel_l2(f[4], u[4]) < noise
+    q1o, p1o, _ = c.oracle.Hamiltonian_EoM(c.q0, c.p0, c.eps, neps)
+    assert rel_l2(f[0], q1o) < TOL_TRAJ_10 and rel_l2(f[1], p1o) < TOL_TRAJ_10
+
+
 def test_epsilon_is_clipped_at_two():
     """HMC.cc:263-264."""
     c = Case(Nx=8, likelihood=3)
