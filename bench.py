@@ -42,7 +42,7 @@ def parse():
     return ap.parse_args()
 
 
-def pmc_traffic(nx):
+def pmc_traffic(nx, precision):
     """HBM bytes per leapfrog step from the newest committed rocprofv3 PMC summary (profiles/r*_pmc_traffic.json,
     made by scripts/pmc_traffic.py from separate FETCH_SIZE / WRITE_SIZE passes of this bench command).
     Returns None when no summary exists for this grid."""
@@ -53,7 +53,7 @@ def pmc_traffic(nx):
             d = json.load(open(path))
         except (OSError, ValueError):
             continue
-        if d.get("grid", 256) == nx:
+        if d.get("grid", 256) == nx and d.get("precision", "fp64") == precision:
             best = (path, d)
     if best is None:
         return None, None
@@ -197,7 +197,8 @@ def main():
         value = steps_total / wall
         algo = ALGO_BYTES_PER_CELL_STEP // (2 if args.fp32 else 1)  # 272 N bytes per step with fp32 fields
         achieved = algo * N * args.steps / (gpu_ms * 1e-3) / 1e9  # per GPU, device time
-        traffic, traffic_src = pmc_traffic(params.Nx) if (rsd and params.likelihood == 1) else (None, None)
+        traffic, traffic_src = (pmc_traffic(params.Nx, "fp32" if args.fp32 else "fp64")
+                                if (rsd and params.likelihood == 1) else (None, None))
         out = {
             "metric": "HMC leapfrog steps/sec on %d^3 grid" % params.Nx,
             "value": round(value, 4),

@@ -2,7 +2,7 @@
 """Turn two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs of the same bench command) into
 HBM bytes per leapfrog step, per kernel and in total.
 
-    python scripts/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <steps> [out.json]
+    python scripts/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <steps> [out.json [grid [fp64|fp32]]]
 
 Counter units and gfx950 corrections follow /opt/skills/guides/MI355X_MICROARCH.md section HBM:
   * FETCH_SIZE / WRITE_SIZE are in KiB (bytes = value * 1024);
@@ -10,8 +10,8 @@ Counter units and gfx950 corrections follow /opt/skills/guides/MI355X_MICROARCH.
     WRITE_SIZE reads exactly for streaming stores and float atomics.
 The doubling is calibrated for 16 B/lane streaming reads; our k-space kernels (double2 per lane) match that
 pattern, 8 B/lane kernels are cross-checked against their known byte counts in the printed table.
-Only the dispatches of the timed trajectory's step loop are counted: from the first k_kick_drift_za<true>
-after the last k_init_ctl up to the last k_assemble<true>.
+Only the dispatches of the timed trajectory's step loop are counted: from the first k_kick_drift_za after the
+last k_init_ctl (the initial force evaluation lies before it) up to the last k_step_boundary / k_assemble.
 """
 import csv
 import json
@@ -22,7 +22,7 @@ from collections import defaultdict
 
 def short(name):
     name = re.sub(r"^void ", "", name)
-    m = re.match(r"(bchmc::)?([A-Za-z0-9_]+(<[a-z]+>)?)", name)
+    m = re.match(r"(bchmc::)?([A-Za-z0-9_]+(<[a-z0-9, ]+>)?)", name)
     return m.group(2) if m else name[:40]
 
 
@@ -31,8 +31,10 @@ def load(path, counter):
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
     names = [short(r["Kernel_Name"]) for r in rows]
     start = max(i for i, n in enumerate(names) if n == "k_init_ctl")
-    first = next(i for i in range(start, len(names)) if names[i] == "k_kick_drift_za<true>")
-    last = max(i for i, n in enumerate(names) if n == "k_assemble<true>")
+    drift = re.compile(r"k_kick_drift_za<(double, |float, )?true>")
+    first = next(i for i in range(start, len(names)) if drift.fullmatch(names[i]))
+    end = re.compile(r"k_step_boundary<.*>|k_assemble<(double, |float, )?true>")
+    last = max(i for i, n in enumerate(names) if end.fullmatch(n))
     per = defaultdict(lambda: [0.0, 0])
     for r, n in zip(rows[first:last + 1], names[first:last + 1]):
         per[n][0] += float(r["Counter_Value"]) * 1024.0
@@ -53,7 +55,9 @@ def main():
                           launches_per_step=round(calls, 2))
         tot_r += r
         tot_w += w
-    out = dict(steps=steps, hbm_read_bytes_per_step=tot_r, hbm_write_bytes_per_step=tot_w,
+    grid = int(sys.argv[5]) if len(sys.argv) > 5 else 256
+    precision = sys.argv[6] if len(sys.argv) > 6 else "fp64"
+    out = dict(grid=grid, precision=precision, steps=steps, hbm_read_bytes_per_step=tot_r, hbm_write_bytes_per_step=tot_w,
                hbm_bytes_per_step=tot_r + tot_w, fetch_size_correction=2.0, kernels=kernels)
     print("%-34s %10s %10s %8s" % ("kernel", "read MB", "write MB", "launches"))
     for n, k in kernels.items():
