@@ -87,6 +87,8 @@ struct bchmc_handle {
   bool hull_exact = false;  // no cell of the (2 reach + 1)^3 cube outside the hull can pass r/h <= 2
   // tile-sorted particle-mesh path
   bool tiled = false;
+  bool disp_alpt = false;    // Ck holds an ALPT displacement: forward_rest applies cellboundcomp after the C2R
+  double alpt_wtot = 0.;     // kernelcomp's normalisation (sum of the real-space kernel), computed on first use
   bool std81 = false;  // standard 81-cell hull on 8 x 8 x 16 tiles with halo 2: fully unrolled scatter/gather kernels
   TilePar tp{};
   int *t_cnt = nullptr, *t_off = nullptr, *t_woff = nullptr;  // ntiles, ntiles+1, ntiles+1
@@ -385,7 +387,7 @@ struct Pipe {
 
   // ---- building blocks of one force / energy evaluation ----
 
-  // Psi^ from the current q^ (no kick, no drift)
+  // Psi^ from the current q^ (no kick, no drift), Zel'dovich: Lag2Eul.cc:88-89 + theta2vel
   static int launch_za(bchmc_handle *h, double dq_factor) {
     ProfScope ps(h, BCHMC_K_KSPACE_DRIFT_ZA);
     StepCtl ctl{h->stop, h->steps_done, nullptr, 0., 0};
@@ -393,6 +395,57 @@ struct Pipe {
     k_kick_drift_za<T, false><<<nblk_stride(h->g.Nhp), 256, 0, h->stream>>>(h->g, C(h->qk), C(h->pk), C(h->gk), nullptr,
                                                                           nullptr, C(h->Ck), 0., 0., c_za, ctl);
     HIPCHK(hipGetLastError());
+    h->disp_alpt = false;
+    return BCHMC_OK;
+  }
+
+  // Which structure-formation model a forward evaluation uses (dispatcher Lag2Eul.cc:325-331; the RSD routine is
+  // Zel'dovich whatever sfmodel says, HMC_models.cc:395-405).
+  static bool uses_alpt(const bchmc_handle *h, int rsd) { return !rsd && h->c.sfmodel != 1; }
+
+  // Psi^ of the forward model selected by (sfmodel, rsd) from the current q^
+  static int displacement(bchmc_handle *h, double dq_factor, int rsd) {
+    return uses_alpt(h, rsd) ? launch_alpt(h, dq_factor) : launch_za(h, dq_factor);
+  }
+
+  // ALPT displacement in k-space (Lag2Eul_non_zeldovich, Lag2Eul.cc:160-267); scratch: plike, rho, V, tC.
+  static int launch_alpt(bchmc_handle *h, double dq_factor) {
+    const long long N = h->g.N, Nhp = h->g.Nhp;
+    const double smol = h->c.kth;
+    if (h->alpt_wtot == 0.) {
+      // kernelcomp: wtot = sum over the box of the inverse transform of the kernel table (= K(0) up to round-off)
+      ProfScope ps(h, BCHMC_K_OTHER);
+      k_alpt_kernel_table<T><<<nblk_stride(Nhp), 256, 0, h->stream>>>(h->g, C(h->tC), smol);
+      HIPCHK(hipGetLastError());
+      CHK(fft_exec(h, h->c2r1, h->tC, h->rho, BCHMC_K_FFT_C2R));
+      k_sum<T><<<kRedBlocks, 256, 0, h->stream>>>(R(h->rho), N, h->partA);
+      HIPCHK(hipGetLastError());
+      double v;
+      CHK(host_sum(h, h->partA, &v));
+      h->alpt_wtot = v / (double)N;
+    }
+    CT *Ck = C(h->Ck);
+    {
+      ProfScope ps(h, BCHMC_K_KSPACE_DRIFT_ZA);
+      k_alpt_poisson<T><<<nblk_stride(Nhp), 256, 0, h->stream>>>(h->g, C(h->qk), Ck, Ck + Nhp, dq_factor / (double)N);
+      HIPCHK(hipGetLastError());
+    }
+    CHK(fft_exec(h, h->c2r1, Ck, h->plike, BCHMC_K_FFT_C2R));        // delta(1)
+    CHK(fft_exec(h, h->c2r1, Ck + Nhp, h->rho, BCHMC_K_FFT_C2R));    // Phi(1)
+    {
+      ProfScope ps(h, BCHMC_K_OTHER);
+      k_alpt_grad<T><<<nblk_stride(N), 256, 0, h->stream>>>(h->g, R(h->rho), R(h->V));
+      k_alpt_sources<T><<<nblk_stride(N), 256, 0, h->stream>>>(h->g, R(h->V), R(h->plike), R(h->rho), h->c.D1, h->c.D2);
+      HIPCHK(hipGetLastError());
+    }
+    CHK(fft_exec(h, h->r2c1, h->rho, Ck, BCHMC_K_FFT_R2C));          // A^ = FFT[D1 delta(1) - D2 delta(2)]
+    CHK(fft_exec(h, h->r2c1, h->plike, Ck + Nhp, BCHMC_K_FFT_R2C));  // B^ = FFT[spherical-collapse source]
+    {
+      ProfScope ps(h, BCHMC_K_KSPACE_DRIFT_ZA);
+      k_alpt_mix<T><<<nblk_stride(Nhp), 256, 0, h->stream>>>(h->g, Ck, smol, 1. / h->alpt_wtot, 1. / (double)N);
+      HIPCHK(hipGetLastError());
+    }
+    h->disp_alpt = true;
     return BCHMC_OK;
   }
 
@@ -400,6 +453,14 @@ struct Pipe {
   static int forward_rest(bchmc_handle *h, int rsd) {
     if (rsd && !h->c.planepar) return h->fail(BCHMC_ERR_RSD_NOT_PLANEPAR, "non-plane-parallel RSD is not implemented");
     CHK(fft_exec(h, h->c2r3, h->Ck, h->psi, BCHMC_K_FFT_C2R));
+    if (h->disp_alpt) {
+      if (rsd) return h->fail(BCHMC_ERR_STATE, "ALPT displacement with the RSD routine");
+      ProfScope ps(h, BCHMC_K_OTHER);
+      k_alpt_cellbound<T><<<nblk_stride(h->g.N), 256, 0, h->stream>>>(h->g, R(h->psi), R(h->V));
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipMemcpyAsync(h->psi, h->V, 3 * (size_t)h->g.N * sizeof(T), hipMemcpyDeviceToDevice, h->stream));
+      h->disp_alpt = false;
+    }
     h->sorted_valid = false;
     const PosPar pp = make_pos(h, rsd);
     const SphPar sp = make_sph(h);
@@ -577,7 +638,7 @@ struct Pipe {
       *b = h->c.grad_psi_likeli_factor;
       return BCHMC_OK;
     }
-    if (!pre_za) CHK(launch_za(h, h->c.deltaQ_factor));
+    if (!pre_za) CHK(displacement(h, h->c.deltaQ_factor, h->c.rsd_model));
     CHK(forward_rest(h, h->c.rsd_model));
     CHK(like_force(h, like_mode));
     double norm = -1.;  // zeldovich_norm, HMC_models.cc:458-461
@@ -667,7 +728,8 @@ struct Pipe {
     if (tap && tap->like_i) CHK(tap_loglike(h, tap->like_i));
     CHK(launch_assemble<false>(h, a, b, like_mode, 0., nullptr));
 
-    const bool fused_za = (h->c.likelihood != 3);
+    // the k-space kernels produce the Zel'dovich Psi^ as a by-product; the ALPT model needs its own pipeline
+    const bool fused_za = (h->c.likelihood != 3) && !uses_alpt(h, h->c.rsd_model);
     const double *wM = h->mass_fs ? h->wM : nullptr;
     const double c_za = -h->c.D1 * h->c.deltaQ_factor / (double)h->g.N;
     const double guard_limit = 1e50 * (double)h->g.N;
@@ -845,7 +907,7 @@ struct Pipe {
       }
       if (done < neps) {
         // runaway guard fired (HMC.cc:360-364): the tapped forward model is not the final state's; redo it
-        CHK(launch_za(h, h->c.likelihood == 1 ? h->c.deltaQ_factor : 1.));
+        CHK(displacement(h, h->c.likelihood == 1 ? h->c.deltaQ_factor : 1., h->c.likelihood == 1 ? h->c.rsd_model : 0));
         CHK(forward_rest(h, h->c.likelihood == 1 ? h->c.rsd_model : 0));
         CHK(tap_loglike(h, P));
         CHK(host_sum(h, P, &terms[5]));
@@ -905,7 +967,7 @@ struct Pipe {
       // gaussian log_like applies deltaQ_factor and honours rsd_model (gaussian_independent.cpp:57-76);
       // poissonian / log-normal log_like do neither (poissonian.cpp:54-56, lognormal_independent.cpp:105-107)
       const bool gauss = (h->c.likelihood == 1);
-      CHK(launch_za(h, gauss ? h->c.deltaQ_factor : 1.));
+      CHK(displacement(h, gauss ? h->c.deltaQ_factor : 1., gauss ? h->c.rsd_model : 0));
       CHK(forward_rest(h, gauss ? h->c.rsd_model : 0));
       k_loglike<T><<<kRedBlocks, 256, 0, h->stream>>>(h->g, make_like(h), R(h->rho), h->rho_part,
                                                       R(h->in_arr[BCHMC_F_NOBS]), R(h->in_arr[BCHMC_F_NOISE]),
@@ -921,7 +983,7 @@ struct Pipe {
 
   static int forward(bchmc_handle *h, const double *d_q, int rsd) {
     CHK(r2c_state(h, d_q, h->ioq, h->qk));
-    CHK(launch_za(h, 1.));
+    CHK(displacement(h, 1., rsd));
     return forward_rest(h, rsd);
   }
 
@@ -1017,9 +1079,9 @@ int validate_config(const bchmc_config *c, std::string &why) {
     why = "likelihood must be 0..3";
     return BCHMC_ERR_ARG;
   }
-  if (!c->rsd_model && c->sfmodel != 1 && c->likelihood != 3) {
-    why = "sfmodel != 1 (ALPT forward model) is not built; Zel'dovich only";
-    return BCHMC_ERR_UNSUPPORTED;
+  if (!c->rsd_model && c->sfmodel != 1 && !(c->kth > 0.)) {
+    why = "sfmodel != 1 (ALPT) needs the split scale kth = slength > 0";
+    return BCHMC_ERR_ARG;
   }
   if (c->particle_kernel_h > c->L / 4) {
     why = "particle_kernel_h of more than Nx/4 cells (init_par.cc:373-375)";
@@ -1345,8 +1407,6 @@ int bchmc_delta_hamiltonian(bchmc_handle *h, const double *qi, const double *pi,
 int bchmc_forward(bchmc_handle *h, const double *q, int use_rsd) {
   if (!h || !q) return BCHMC_ERR_ARG;
   ENTER(h);
-  if (h->c.likelihood == 3 && h->c.sfmodel != 1 && !h->c.rsd_model)
-    return h->fail(BCHMC_ERR_UNSUPPORTED, "sfmodel != 1 forward model is not built");
   HIPCHK(hipMemcpyAsync(h->dstage, q, h->g.N * sizeof(double), hipMemcpyHostToDevice, h->stream));
   CHK(DISPATCH(h, forward(h, h->dstage, use_rsd < 0 ? h->c.rsd_model : (use_rsd ? 1 : 0))));
   HIPCHK(hipStreamSynchronize(h->stream));

@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must precede loading libbarcode_hip.so, see module 
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbarcode_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 FIELDS = dict(signal_PS=0, mass_f=1, mass_r=2, nobs=3, noise=4, window=5, deltaX=6, posx=7, posy=8, posz=9,
               rho=10, part_like=11, Vx=12, Vy=13, Vz=14, psix=15, psiy=16, psiz=17, grad_prior=18, grad_like=19)
@@ -35,6 +35,7 @@ class BchmcConfig(C.Structure):
         ("deltaQ_factor", C.c_double),
         ("rho_c", C.c_double), ("delta_min", C.c_double), ("biasP", C.c_double), ("biasE", C.c_double),
         ("ascale", C.c_double), ("D1", C.c_double), ("D2", C.c_double), ("OM", C.c_double), ("OL", C.c_double),
+        ("kth", C.c_double),
         ("precision", C.c_int32), ("device", C.c_int32),
     ]
 

@@ -26,7 +26,8 @@ class HamilParams:
     calc_h: int = 2
     likelihood: int = 1        # 0 Poisson, 1 Gaussian, 2 log-normal, 3 GRF
     prior: int = 0             # only the Gaussian prior exists upstream (init_par.cc:582-588)
-    sfmodel: int = 1
+    sfmodel: int = 1           # 1 Zel'dovich, anything else ALPT (Lag2Eul.cc:325-331); ignored when rsd_model is set
+    kth: float = 4.0           # = slength (input.par:121, struct_hamil.h:259): ALPT split scale
     rsd_model: int = 0
     mass_type: int = 1
     correct_delta: int = 1

@@ -32,6 +32,8 @@ def parse():
     ap.add_argument("--nx", type=int, default=256, help="grid cells per axis (BASELINE config 3: 256)")
     ap.add_argument("--likelihood", type=int, default=1)
     ap.add_argument("--no-rsd", action="store_true")
+    ap.add_argument("--alpt", action="store_true",
+                    help="with --no-rsd: sfmodel = 2, the ALPT forward model (Lag2Eul_non_zeldovich) in every force evaluation")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-nx", type=int, default=0, help="grid of the CPU-baseline sample (default: same as --nx)")
     ap.add_argument("--no-kernel-profile", action="store_true")
@@ -114,7 +116,7 @@ def main():
     rsd = 0 if args.no_rsd else 1
     # BASELINE config 3: "256^3, 2LPT + RSD": under rsd_model the reference dispatches to Zel'dovich + plane-parallel
     # RSD whatever sfmodel says; Gaussian likelihood, SPH kernel, calc_h 2, mass_type 1, fp64.
-    params = HamilParams(Nx=args.nx, L=200.0, likelihood=args.likelihood, rsd_model=rsd, sfmodel=2 if rsd else 1)
+    params = HamilParams(Nx=args.nx, L=200.0, likelihood=args.likelihood, rsd_model=rsd, sfmodel=2 if (rsd or args.alpt) else 1)
     group = ChainGroup(pool=True, device=dev if args.backend == "nccl" else torch.device("cpu"))
     ring = EpsRing()
 
@@ -213,9 +215,12 @@ def main():
             "dtype": "f32" if args.fp32 else "f64",
             "data": "synthetic",
             "config": {
-                "workload": "%d^3 grid, L=200 Mpc/h, Gaussian prior, Zel'dovich%s (reference behaviour of '2LPT+RSD', "
-                            "SURVEY M3), likelihood=%d, SPH mass kernel (mk=3), calc_h=2, mass_type=1, %s; one "
-                            "trajectory of %d leapfrog steps per chain" % (params.Nx, " + plane-parallel RSD" if rsd else "",
+                "workload": "%d^3 grid, L=200 Mpc/h, Gaussian prior, %s, likelihood=%d, SPH mass kernel (mk=3), calc_h=2, mass_type=1, %s; one "
+                            "trajectory of %d leapfrog steps per chain" % (params.Nx,
+                                                                           ("Zel'dovich + plane-parallel RSD (reference "
+                                                                            "behaviour of '2LPT+RSD', SURVEY M3)") if rsd else
+                                                                           ("ALPT forward model (sfmodel=2, kth=4)"
+                                                                            if args.alpt else "Zel'dovich"),
                                                                            params.likelihood,
                                                                            "fp32 field arrays" if args.fp32 else "fp64",
                                                                            args.steps),

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define BCHMC_ABI_VERSION 1
+#define BCHMC_ABI_VERSION 2
 
 /* Scalars of HAMIL_NUMERICAL / HAMIL_DATA read by the path (barlib/include/struct_hamil.h:51-222);
  * filled by the shim from the HAMIL_DATA that call_hamil.cc:42 builds.  Cubic grids only, like the
@@ -35,7 +35,8 @@ typedef struct bchmc_config {
   int32_t mk;                /* masskernel: 0 NGP, 1 CIC, 2 TSC, 3 SPH */
   int32_t calc_h;            /* 0 (legacy), 1, 2 (SPH adjoint, default) or 3 (Fourier + TSC) */
   int32_t likelihood;        /* 0 Poisson, 1 Gaussian, 2 log-normal, 3 GRF (init_par.cc:534-559) */
-  int32_t sfmodel;           /* 1 Zel'dovich (others only together with rsd_model) */
+  int32_t sfmodel;           /* 1 Zel'dovich; anything else: ALPT (Lag2Eul_non_zeldovich, Lag2Eul.cc:138-312, dispatcher
+                              * 325-331) unless rsd_model is set, which always takes the Zel'dovich + RSD model */
   int32_t rsd_model;
   int32_t mass_type;         /* 0,1,2,3,4,5,6,60 -> mass_fs/mass_rs as struct_hamil.h:272-313 */
   int32_t correct_delta;
@@ -44,6 +45,7 @@ typedef struct bchmc_config {
   double grad_psi_prior_factor, grad_psi_likeli_factor, deltaQ_factor;
   double rho_c, delta_min, biasP, biasE;
   double ascale, D1, D2, OM, OL;
+  double kth;                /* ALPT split scale [Mpc/h] = n->kth = slength (struct_hamil.h:102,259; input.par:121) */
   int32_t precision;         /* 0: fp64 field arrays (reference DOUBLE_PREC); 1: fp32 field arrays (SINGLE_PREC-like:
                               * storage + particle-mesh arithmetic in float, k-space arithmetic and reductions in
                               * double).  The ABI's arrays are double in both modes. */

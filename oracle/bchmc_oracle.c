@@ -565,6 +565,8 @@ void orc_overdens(orc_hamil *h, const double *in, double *out) {
   for (long i = 0; i < (long)h->N; i++) out[i] = in[i] / nmean - 1.;
 }
 
+int orc_alpt_displacement(orc_hamil *h, const double *in, double *psix, double *psiy, double *psiz);
+
 /* ------------------------------------------------------------------------------------------------
  * a6: Lag2Eul.cc:69-132 (Zel'dovich), 338-424 (Zel'dovich + plane-parallel RSD), dispatcher 318-332.
  * `in` may alias C2R_R (as in HMC_models.cc:383-405); `out` receives delta_x.
@@ -572,9 +574,12 @@ void orc_overdens(orc_hamil *h, const double *in, double *out) {
 int orc_Lag2Eul(orc_hamil *h, const double *in, double *out, double *posx, double *posy, double *posz, int use_rsd) {
   const size_t N = h->N;
   int rc = ORC_OK;
-  if (!use_rsd && h->c.sfmodel != 1) return ORC_ERR_UNSUPPORTED; /* ALPT forward model: SURVEY 8f-3 */
   double *psix = dalloc(N), *psiy = dalloc(N), *psiz = dalloc(N);
-  if (!use_rsd) {
+  if (!use_rsd && h->c.sfmodel != 1) { /* Lag2Eul_non_zeldovich, Lag2Eul.cc:138-312 (dispatcher 325-331) */
+    copyArray(in, out, N); /* 166: `dummy` is the output array */
+    orc_alpt_displacement(h, out, psix, psiy, psiz);
+    disp_part(h, posx, posy, posz, psix, psiy, psiz);
+  } else if (!use_rsd) {
     multiply_factor_array(-h->c.D1, in, out, N); /* 88 */
     orc_theta2vel(h, out, psix, psiy, psiz);
     disp_part(h, posx, posy, posz, psix, psiy, psiz);
@@ -919,6 +924,189 @@ static void gradfindif(orc_hamil *h, const double *in, double *out, unsigned dim
         out[IX(c)] = -(fac * ((4.0 / 3) * (in[IX(l)] - in[IX(r)]) - (1.0 / 6) * (in[IX(ll)] - in[IX(rr)])));
 #undef IX
       }
+}
+
+/* ================================================================================================
+ * f-3: ALPT forward model (Lag2Eul_non_zeldovich, Lag2Eul.cc:138-312; default build: GFINDIFF, no TRANSF)
+ * ============================================================================================== */
+static double k_squared_full(const orc_hamil *h, unsigned i, unsigned j, unsigned k) {
+  double kx = calc_ki(i, h->L1, h->N1), ky = calc_ki(j, h->L2, h->N2), kz = calc_ki(k, h->L3, h->N3);
+  return kx * kx + ky * ky + kz * kz;
+}
+
+/* EqSolvers.cc:29-64: Pot = IFFT[-delta^ / k^2], k = 0 -> 0 */
+int orc_PoissonSolver(orc_hamil *h, const double *delta, double *Pot) {
+  const unsigned N1 = h->N1, N2 = h->N2, N3half = h->N3 / 2 + 1;
+  double *C = dalloc(2 * h->Nhalf), *R = dalloc(h->N);
+  copyArray(delta, R, h->N);
+  orc_fft_r2c_3d(h->N1, h->N2, h->N3, R, C);
+#pragma omp parallel for
+  for (long i = 0; i < (long)N1; i++)
+    for (unsigned j = 0; j < N2; j++)
+      for (unsigned k = 0; k < N3half; ++k) {
+        size_t ix = k + (size_t)N3half * (j + (size_t)N2 * i);
+        double kmod2 = k_squared_full(h, (unsigned)i, j, k);
+        double fackern = 0.;
+        if (kmod2 > 0.) fackern = -1. / kmod2;
+        C[2 * ix] *= fackern;
+        C[2 * ix + 1] *= fackern;
+      }
+  orc_fft_c2r_3d(h->N1, h->N2, h->N3, C, Pot);
+  multiply_factor_array(1 / (double)h->N, Pot, Pot, h->N); /* fftC2R, fftwrapper.cc:44-46 */
+  free(C);
+  free(R);
+  return ORC_OK;
+}
+
+/* EqSolvers.cc:373-422, GFINDIFF branch (cmake/Modules/Options.cmake:92-93: GFFT OFF, GFINDIFF ON) */
+int orc_calc_m2v_mem(orc_hamil *h, const double *phiv, double *m2v) {
+  const size_t N = h->N;
+  double *xx = dalloc(N), *yy = dalloc(N), *zz = dalloc(N), *xy = dalloc(N), *xz = dalloc(N), *yz = dalloc(N);
+  double *dummy = dalloc(N);
+  gradfindif(h, phiv, dummy, 1);
+  gradfindif(h, dummy, xx, 1);
+  gradfindif(h, dummy, xy, 2);
+  gradfindif(h, dummy, xz, 3);
+  gradfindif(h, phiv, dummy, 2);
+  gradfindif(h, dummy, yy, 2);
+  gradfindif(h, dummy, yz, 3);
+  gradfindif(h, phiv, dummy, 3);
+  gradfindif(h, dummy, zz, 3);
+#pragma omp parallel for
+  for (long i = 0; i < (long)N; i++)
+    m2v[i] = xx[i] * yy[i] - xy[i] * xy[i] + xx[i] * zz[i] - xz[i] * xz[i] + yy[i] * zz[i] - yz[i] * yz[i];
+  free(xx); free(yy); free(zz); free(xy); free(xz); free(yz); free(dummy);
+  return ORC_OK;
+}
+
+/* convolution.cpp:224-324 with filtertype 1 (barcoderunner.cc:371-374): K(k) = exp(-k^2 smol^2 / 2) on the FULL
+ * n^3 grid, divided by the sum of its inverse transform (= K(0) = 1 up to round-off).  The reference writes this
+ * table to `auxkernelr<int(smol)>` and convcomp reads it back; the file is a raw dump, so nothing changes. */
+int orc_kernelcomp(orc_hamil *h, double smol, double *out) {
+  const unsigned N1 = h->N1, N2 = h->N2, N3 = h->N3, N3half = N3 / 2 + 1;
+  const double rS2 = smol * smol;
+#pragma omp parallel for
+  for (long i = 0; i < (long)N1; i++)
+    for (unsigned j = 0; j < N2; j++)
+      for (unsigned k = 0; k < N3; k++)
+        out[k + (size_t)N3 * (j + (size_t)N2 * i)] = exp(-k_squared_full(h, (unsigned)i, j, k) * rS2 / 2.);
+  /* FFT3d(to_Rspace) of the (real, even) table and the sum of the result: the table is Hermitian, so its
+   * half-complex part transformed with c2r and scaled by 1/N is the same real array. */
+  double *C = dalloc(2 * h->Nhalf), *R = dalloc(h->N);
+  for (unsigned i = 0; i < N1; i++)
+    for (unsigned j = 0; j < N2; j++)
+      for (unsigned k = 0; k < N3half; k++)
+        C[2 * (k + (size_t)N3half * (j + (size_t)N2 * i))] = out[k + (size_t)N3 * (j + (size_t)N2 * i)];
+  orc_fft_c2r_3d(N1, N2, N3, C, R);
+  double wtot = 0.;
+  for (size_t i = 0; i < h->N; i++) wtot += R[i] / (double)h->N;
+  for (size_t i = 0; i < h->N; i++) out[i] /= wtot;
+  free(C);
+  free(R);
+  return ORC_OK;
+}
+
+/* convolution.cpp:327-377: out = IFFT[FFT[in] * kernel]; the reference uses full complex transforms of the real
+ * input, of which the half-complex part carries everything. */
+int orc_convcomp(orc_hamil *h, const double *in, double *out, double smol) {
+  const unsigned N1 = h->N1, N2 = h->N2, N3 = h->N3, N3half = N3 / 2 + 1;
+  double *kern = dalloc(h->N), *C = dalloc(2 * h->Nhalf), *R = dalloc(h->N);
+  orc_kernelcomp(h, smol, kern);
+  copyArray(in, R, h->N);
+  orc_fft_r2c_3d(N1, N2, N3, R, C);
+#pragma omp parallel for
+  for (long i = 0; i < (long)N1; i++)
+    for (unsigned j = 0; j < N2; j++)
+      for (unsigned k = 0; k < N3half; k++) {
+        size_t ix = k + (size_t)N3half * (j + (size_t)N2 * i);
+        double kv = kern[k + (size_t)N3 * (j + (size_t)N2 * i)];
+        C[2 * ix] *= kv;
+        C[2 * ix + 1] *= kv;
+      }
+  orc_fft_c2r_3d(N1, N2, N3, C, out);
+  multiply_factor_array(1 / (double)h->N, out, out, h->N); /* FFT3dC2R, fftwrapper.cc:238 */
+  free(kern); free(C); free(R);
+  return ORC_OK;
+}
+
+/* EqSolvers.cc:280-368 with zeropad = false, norm = false (cpecvel = 1) */
+int orc_theta2velcomp(orc_hamil *h, const double *delta, double *vei, int comp) {
+  const unsigned N1 = h->N1, N2 = h->N2, N3 = h->N3, N3half = N3 / 2 + 1;
+  if (comp < 1 || comp > 3) return ORC_ERR_ARG;
+  double *C = dalloc(2 * h->Nhalf), *R = dalloc(h->N);
+  copyArray(delta, R, h->N);
+  orc_fft_r2c_3d(N1, N2, N3, R, C);
+#pragma omp parallel for
+  for (long i = 0; i < (long)N1; i++)
+    for (unsigned j = 0; j < N2; j++)
+      for (unsigned k = 0; k < N3half; k++) {
+        size_t ix = k + (size_t)N3half * (j + (size_t)N2 * i);
+        double kx = calc_ki((unsigned)i, h->L1, N1), ky = calc_ki(j, h->L2, N2), kz = calc_ki(k, h->L3, N3);
+        double kl = comp == 1 ? kx : (comp == 2 ? ky : kz);
+        double kmod2 = kx * kx + ky * ky + kz * kz;
+        double fackern = 0.0; /* linearvel3d, EqSolvers.cc:130-165 */
+        if (kmod2 > EPS_KSQ) fackern = kl / kmod2;
+        double dr = C[2 * ix], di = C[2 * ix + 1];
+        C[2 * ix] = fackern * di;
+        C[2 * ix + 1] = fackern * -dr;
+        if (((unsigned)i == N1 / 2) || (j == N2 / 2) || (k == N3 / 2)) C[2 * ix] = C[2 * ix + 1] = 0.;
+      }
+  orc_fft_c2r_3d(N1, N2, N3, C, vei);
+  multiply_factor_array(1 / (double)h->N, vei, vei, h->N);
+  free(C); free(R);
+  return ORC_OK;
+}
+
+/* massFunctions.cc:588-658: vi[l] <- (vi[l] + vi[l - (1,1,1)]) / 2, periodic */
+int orc_cellboundcomp(orc_hamil *h, double *vi) {
+  const int N1 = (int)h->N1, N2 = (int)h->N2, N3 = (int)h->N3;
+  double *viout = dalloc(h->N);
+#pragma omp parallel for
+  for (long i = 0; i < N1; i++)
+    for (int j = 0; j < N2; j++)
+      for (int k = 0; k < N3; k++) {
+        size_t l = (size_t)k + (size_t)N3 * ((size_t)j + (size_t)N2 * (size_t)i);
+        int im = (int)i > 0 ? (int)i - 1 : N1 - 1, jm = j > 0 ? j - 1 : N2 - 1, km = k > 0 ? k - 1 : N3 - 1;
+        size_t m = (size_t)km + (size_t)N3 * ((size_t)jm + (size_t)N2 * (size_t)im);
+        viout[l] = 0.5 * (vi[m] + vi[l]);
+      }
+  copyArray(viout, vi, h->N);
+  free(viout);
+  return ORC_OK;
+}
+
+/* Lag2Eul.cc:160-267: Psi^tot = K o Psi^2LPT + Psi^SC - K o Psi^SC per component, then cellboundcomp.
+ * `in` is delta^(1); it is left untouched here (the reference works on a copy, 166). */
+int orc_alpt_displacement(orc_hamil *h, const double *in, double *psix, double *psiy, double *psiz) {
+  const size_t N = h->N;
+  const double D1 = h->c.D1, D2 = h->c.D2, kth = h->c.kth, kthsc = h->c.kth;
+  double *dummy = dalloc(N), *dummy2 = dalloc(N), *dummy3 = dalloc(N), *dummy4 = dalloc(N);
+  copyArray(in, dummy, N);
+  orc_PoissonSolver(h, dummy, dummy2);   /* delta(1) -> Phi(1)   169 */
+  orc_calc_m2v_mem(h, dummy2, dummy3);   /* Phi(1)  -> delta(2)  171 */
+  for (size_t i = 0; i < N; i++) dummy2[i] = D1 * dummy[i] - D2 * dummy3[i]; /* div Psi^2LPT, 199-200 */
+  orc_convcomp(h, dummy2, dummy2, kth);  /* K o div Psi^2LPT, 203 */
+  for (size_t i = 0; i < N; i++) {       /* div Psi^SC, 212-226 */
+    double psilin = -D1 * dummy[i];
+    double psisc = 0.;
+    if (1. + 2. / 3. * psilin > 0.)
+      psisc = 3. * (sqrt(1. + 2. / 3. * psilin) - 1.);
+    else
+      psisc = -3.;
+    psisc *= -1.;
+    dummy4[i] = psisc;
+  }
+  double *psi[3] = {psix, psiy, psiz};
+  for (int c = 1; c <= 3; c++) {         /* 240-281 */
+    orc_theta2velcomp(h, dummy2, dummy3, c);  /* K o Psi^2LPT_c */
+    orc_theta2velcomp(h, dummy4, dummy, c);   /* Psi^SC_c */
+    add_to_array(dummy, dummy3, N);           /* K o Psi^2LPT_c + Psi^SC_c */
+    orc_convcomp(h, dummy, dummy, kthsc);     /* K o Psi^SC_c */
+    for (size_t i = 0; i < N; i++) psi[c - 1][i] = dummy3[i] - dummy[i]; /* subtract_arrays */
+    orc_cellboundcomp(h, psi[c - 1]);
+  }
+  free(dummy); free(dummy2); free(dummy3); free(dummy4);
+  return ORC_OK;
 }
 
 /* *_likelihood_grad_f_delta_x_comp: gaussian_independent.cpp:43-50 (gradfft), poissonian.cpp:37-42 (gradfindif),

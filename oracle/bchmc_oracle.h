@@ -28,7 +28,7 @@ typedef struct orc_config {
   int32_t mk;             /* masskernel 0 NGP, 1 CIC, 2 TSC, 3 SPH */
   int32_t calc_h;         /* 0..3 */
   int32_t likelihood;     /* 0 Poisson, 1 Gaussian, 2 log-normal, 3 GRF */
-  int32_t sfmodel;        /* 1 Zel'dovich; others unsupported unless rsd_model */
+  int32_t sfmodel;        /* 1 Zel'dovich; anything else = ALPT (Lag2Eul_non_zeldovich) unless rsd_model */
   int32_t rsd_model;
   int32_t mass_type;      /* -> mass_fs/mass_rs as struct_hamil.h:272-313 */
   int32_t correct_delta;
@@ -37,6 +37,7 @@ typedef struct orc_config {
   double grad_psi_prior_factor, grad_psi_likeli_factor, deltaQ_factor;
   double rho_c, delta_min, biasP, biasE;
   double ascale, D1, D2, OM, OL;
+  double kth;             /* ALPT split scale = slength (struct_hamil.h:259); used when sfmodel != 1 && !rsd_model */
 } orc_config;
 
 enum {
@@ -92,6 +93,15 @@ int orc_Hamiltonian_EoM(orc_hamil *h, const double *qi, const double *pi, double
                         uint64_t Neps, uint64_t *steps_done);
 
 /* scalars of cosmo.cc used by the path */
+/* f-3: the pieces of Lag2Eul_non_zeldovich, Lag2Eul.cc:138-312 */
+int orc_PoissonSolver(orc_hamil *h, const double *delta, double *Pot);             /* EqSolvers.cc:29-64 */
+int orc_calc_m2v_mem(orc_hamil *h, const double *phiv, double *m2v);               /* EqSolvers.cc:373-422 (GFINDIFF) */
+int orc_kernelcomp(orc_hamil *h, double smol, double *kernel_full);                /* convolution.cpp:224-324, Gaussian */
+int orc_convcomp(orc_hamil *h, const double *in, double *out, double smol);        /* convolution.cpp:327-377 */
+int orc_theta2velcomp(orc_hamil *h, const double *delta, double *vei, int comp);   /* EqSolvers.cc:280-368 */
+int orc_cellboundcomp(orc_hamil *h, double *vi);                                   /* massFunctions.cc:588-658 */
+int orc_alpt_displacement(orc_hamil *h, const double *in, double *psix, double *psiy, double *psiz);
+
 double orc_fgrow(double a, double OM, double OL, int term);    /* cosmo.cc:182-217 */
 double orc_c_pecvel(double a, double OM, double OL, int term); /* cosmo.cc:220-235 */
 

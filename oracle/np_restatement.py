@@ -61,10 +61,49 @@ class NpHamil:
         x = np.where(x < 0, np.fmod(x, L) + L, x)
         return np.where(x >= L, np.fmod(x, L), x)
 
+    # ---- f-3: ALPT displacement (Lag2Eul_non_zeldovich, Lag2Eul.cc:160-267), written independently of the C
+    # oracle: derivatives with np.roll, the three filters combined in k-space (everything there is linear) ----
+    def gradfindif(self, a, axis):  # gradient.cpp:81-154: 4th-order central difference
+        fac = self.n / (2.0 * self.L)
+        l, r = np.roll(a, 1, axis), np.roll(a, -1, axis)
+        ll, rr = np.roll(a, 2, axis), np.roll(a, -2, axis)
+        return -(fac * ((4.0 / 3) * (l - r) - (1.0 / 6) * (ll - rr)))
+
+    def alpt_kernel(self, smol):  # convolution.cpp:224-324, Gaussian; sum of its inverse transform = K(0) = 1
+        return np.exp(-self.ksq * smol * smol / 2.0)
+
+    def alpt_displacement(self, delta):
+        p = self.p
+        d1 = delta.reshape(self.shape)
+        inv = np.zeros_like(self.ksq)
+        np.divide(1.0, self.ksq, out=inv, where=self.ksq > 0)
+        phi = self.c2r(-self.r2c(d1) * inv)                                   # PoissonSolver, EqSolvers.cc:29-64
+        g = [self.gradfindif(phi, a) for a in range(3)]                       # calc_m2v_mem, EqSolvers.cc:373-422
+        xx, xy, xz = (self.gradfindif(g[0], a) for a in range(3))
+        yy, yz = self.gradfindif(g[1], 1), self.gradfindif(g[1], 2)
+        zz = self.gradfindif(g[2], 2)
+        d2 = xx * yy - xy * xy + xx * zz - xz * xz + yy * zz - yz * yz
+        div_2lpt = p.D1 * d1 - p.D2 * d2
+        psilin = -p.D1 * d1
+        arg = 1.0 + 2.0 / 3.0 * psilin
+        div_sc = -np.where(arg > 0, 3.0 * (np.sqrt(np.maximum(arg, 0.0)) - 1.0), -3.0)
+        K = self.alpt_kernel(p.kth)
+        mix = K * self.r2c(div_2lpt) + (1.0 - K) * self.r2c(div_sc)           # K o A + B - K o B
+        inv_e = np.zeros_like(self.ksq)
+        np.divide(1.0, self.ksq, out=inv_e, where=self.ksq > 1e-14)           # linearvel3d, EqSolvers.cc:156-160
+        inv_e[self.nyq] = 0.0
+        base = -1j * mix * inv_e
+        psi = [self.c2r(base * k) for k in (self.kx, self.ky, self.kz)]
+        shift = lambda a: 0.5 * (a + np.roll(a, (1, 1, 1), (0, 1, 2)))         # cellboundcomp, massFunctions.cc:588-658
+        return tuple(shift(a) for a in psi)
+
     # Lag2Eul.cc:69-132 / 338-424 + disp_part.cc + rsd.cc
     def positions(self, delta, rsd):
         p = self.p
-        psi = self.theta2vel(-p.D1 * delta.reshape(self.shape))
+        if not rsd and p.sfmodel != 1:
+            psi = self.alpt_displacement(delta)
+        else:
+            psi = self.theta2vel(-p.D1 * delta.reshape(self.shape))
         c = self.d * np.arange(self.n) + 0.5 * self.d
         pos = [self._pacman(c[:, None, None] + psi[0], self.L),
                self._pacman(c[None, :, None] + psi[1], self.L),

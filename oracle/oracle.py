@@ -32,6 +32,7 @@ class OrcConfig(C.Structure):
         ("deltaQ_factor", C.c_double),
         ("rho_c", C.c_double), ("delta_min", C.c_double), ("biasP", C.c_double), ("biasE", C.c_double),
         ("ascale", C.c_double), ("D1", C.c_double), ("D2", C.c_double), ("OM", C.c_double), ("OL", C.c_double),
+        ("kth", C.c_double),
     ]
 
 
@@ -94,6 +95,13 @@ def _lib(omp):
             "orc_psi": [vp, dp, dp, dp],
             "orc_delta_Hamiltonian": [vp, dp, dp, dp, dp, dp, dp],
             "orc_Hamiltonian_EoM": [vp, dp, dp, dp, dp, C.c_double, C.c_uint64, C.POINTER(C.c_uint64)],
+            "orc_PoissonSolver": [vp, dp, dp],
+            "orc_calc_m2v_mem": [vp, dp, dp],
+            "orc_kernelcomp": [vp, C.c_double, dp],
+            "orc_convcomp": [vp, dp, dp, C.c_double],
+            "orc_theta2velcomp": [vp, dp, dp, C.c_int],
+            "orc_cellboundcomp": [vp, dp],
+            "orc_alpt_displacement": [vp, dp, dp, dp, dp],
         }.items():
             getattr(lib, name).argtypes = args
             getattr(lib, name).restype = C.c_int
@@ -188,6 +196,42 @@ class Oracle:
         vx, vy, vz = self._new(), self._new(), self._new()
         self._chk(self.lib.orc_theta2vel(self.h, _p(self._in(delta)), _p(vx), _p(vy), _p(vz)))
         return vx, vy, vz
+
+    # ---- f-3: pieces of Lag2Eul_non_zeldovich (Lag2Eul.cc:138-312) -----------------------------------------
+    def PoissonSolver(self, delta):
+        out = self._new()
+        self._chk(self.lib.orc_PoissonSolver(self.h, _p(self._in(delta)), _p(out)))
+        return out
+
+    def calc_m2v_mem(self, phiv):
+        out = self._new()
+        self._chk(self.lib.orc_calc_m2v_mem(self.h, _p(self._in(phiv)), _p(out)))
+        return out
+
+    def kernelcomp(self, smol):
+        out = self._new()
+        self._chk(self.lib.orc_kernelcomp(self.h, float(smol), _p(out)))
+        return out
+
+    def convcomp(self, a, smol):
+        out = self._new()
+        self._chk(self.lib.orc_convcomp(self.h, _p(self._in(a)), _p(out), float(smol)))
+        return out
+
+    def theta2velcomp(self, delta, comp):
+        out = self._new()
+        self._chk(self.lib.orc_theta2velcomp(self.h, _p(self._in(delta)), _p(out), int(comp)))
+        return out
+
+    def cellboundcomp(self, v):
+        out = self._in(v).copy()
+        self._chk(self.lib.orc_cellboundcomp(self.h, _p(out)))
+        return out
+
+    def alpt_displacement(self, delta):
+        px, py, pz = self._new(), self._new(), self._new()
+        self._chk(self.lib.orc_alpt_displacement(self.h, _p(self._in(delta)), _p(px), _p(py), _p(pz)))
+        return px, py, pz
 
     def Lag2Eul(self, delta, rsd=None):
         out, px, py, pz = (self._new() for _ in range(4))

@@ -5,7 +5,7 @@ PARITY UNPINNED: these vectors come from OUR restatement of the reference (oracl
 the reference itself -- it ships no golden vectors for this path and cannot be built in this image (FFTW3
 and GSL absent).  They pin the oracle against regressions and give the GPU path a fixed target.
 
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py [name ...]        (no names: all of them)
 
 Each <name>.npz holds the scalar parameters, every input array and the outputs of one force evaluation, one
 trajectory (forced Neps, epsilon: SURVEY M5) and delta_Hamiltonian.
@@ -31,6 +31,7 @@ CASES = {
     "gauss_mass5_8": dict(Nx=8, likelihood=1, rsd_model=0, mass_type=5),
     "gauss_calch3_rsd_8": dict(Nx=8, likelihood=1, rsd_model=1, calc_h=3),
     "gauss_cic_calch1_8": dict(Nx=8, likelihood=1, rsd_model=0, calc_h=1, mk=1),
+    "gauss_alpt_8": dict(Nx=8, likelihood=1, rsd_model=0, sfmodel=2),  # ALPT forward model
 }
 NEPS = 10
 
@@ -63,4 +64,5 @@ def make(name, kw):
 
 if __name__ == "__main__":
     for name, kw in CASES.items():
-        make(name, kw)
+        if len(sys.argv) == 1 or name in sys.argv[1:]:
+            make(name, kw)

@@ -20,9 +20,10 @@ def test_philox_known_answers():
 
 @pytest.mark.parametrize("kw", [dict(likelihood=1, rsd_model=1), dict(likelihood=0), dict(likelihood=3),
                                 dict(likelihood=1, mass_type=5), dict(likelihood=1, deltaQ_factor=0.9),
-                                dict(likelihood=2, deltaQ_factor=0.9)],
+                                dict(likelihood=2, deltaQ_factor=0.9), dict(likelihood=1, sfmodel=2),
+                                dict(likelihood=0, rsd_model=1, sfmodel=2, eps_scale=0.01)],
                          ids=["gauss_rsd_fast", "poisson_fast", "grf_generic", "mass5_generic", "gauss_dq_fast",
-                              "lognormal_dq_generic"])
+                              "lognormal_dq_generic", "gauss_alpt_fast", "poisson_rsd_alpt_generic"])
 def test_attempt_equals_leapfrog_plus_delta_hamiltonian(kw):
     """One attempt on the resident chain == Hamiltonian_EoM followed by delta_Hamiltonian on host arrays
     (and hence == the oracle), for the shared-forward-model fast path and the generic fallback."""

@@ -31,6 +31,10 @@ CONFIGS = [
     dict(likelihood=1, rsd_model=1, calc_h=1, mk=2),       # TSC (massFunctions.cc:167-364)
     dict(likelihood=1, rsd_model=1, deltaQ_factor=0.9, grad_psi_prior_factor=0.5, grad_psi_likeli_factor=2.0,
          correct_delta=0),                                 # test factors (HMC.cc:170-173, HMC_models.cc:461-468)
+    dict(likelihood=1, rsd_model=0, sfmodel=2),            # ALPT forward model in force and energies (Lag2Eul.cc:138-312)
+    dict(likelihood=0, rsd_model=0, sfmodel=2, kth=2.0, deltaQ_factor=0.9),
+    dict(likelihood=0, rsd_model=1, sfmodel=2, eps_scale=0.01),  # force: Zel'dovich + RSD; Poissonian log_like: ALPT, no RSD
+                                                                 # (ill-conditioned at the default step: amplification 3e9)
 ]
 
 
@@ -51,7 +55,10 @@ def test_forward_model_intermediates(case):
     rsd = c.p.rsd_model
     dX, px, py, pz = c.oracle.Lag2Eul(c.truth, rsd=rsd)
     c.e.forward(c.truth, rsd)
-    psi = c.oracle.theta2vel(-c.p.D1 * c.truth.ravel())
+    if c.p.sfmodel != 1 and not rsd:
+        psi = c.oracle.alpt_displacement(c.truth)
+    else:
+        psi = c.oracle.theta2vel(-c.p.D1 * c.truth.ravel())
     for name, ref in zip(("psix", "psiy", "psiz"), psi):
         assert rel_l2(c.e.fetch(name), ref) < TOL_FIELD
     for name, ref in zip(("posx", "posy", "posz"), (px, py, pz)):

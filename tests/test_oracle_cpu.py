@@ -16,6 +16,8 @@ CONFIGS = [
     dict(likelihood=1, rsd_model=1),
     dict(likelihood=0, rsd_model=0),
     dict(likelihood=2, rsd_model=0),
+    dict(likelihood=1, rsd_model=0, sfmodel=2),            # ALPT forward model (Lag2Eul_non_zeldovich)
+    dict(likelihood=0, rsd_model=0, sfmodel=2, kth=2.0),
 ]
 
 
@@ -158,3 +160,52 @@ def test_error_codes():
     with pytest.raises(OracleError) as ei:
         Case(Nx=8, mass_type=7)
     assert ei.value.code == 4
+
+
+# ---- f-3: the pieces of Lag2Eul_non_zeldovich (Lag2Eul.cc:138-312) ----------------------------------------
+def test_alpt_pieces_against_independent_numpy_forms():
+    c = Case(Nx=8, likelihood=1, rsd_model=0, sfmodel=2)
+    n, o, p = _np(c), c.oracle, c.p
+    q = c.q0.reshape(n.shape)
+    # PoissonSolver: the spectral Laplacian of the potential gives back delta minus its mean
+    phi = o.PoissonSolver(q).reshape(n.shape)
+    lap = n.c2r(-n.ksq * n.r2c(phi))
+    assert rel_l2(lap, q - q.mean()) < 1e-13
+    # calc_m2v_mem on a plane wave: only the xx term survives, so delta(2) = 0
+    x = (np.arange(p.Nx) + 0.5) * p.d
+    wave = np.sin(2 * np.pi * x / p.L)[:, None, None] * np.ones(n.shape)
+    assert np.abs(o.calc_m2v_mem(wave)).max() < 1e-14
+    # ... and against the np.roll form on a random field
+    g = [n.gradfindif(phi, a) for a in range(3)]
+    xx, xy, xz = (n.gradfindif(g[0], a) for a in range(3))
+    yy, yz, zz = n.gradfindif(g[1], 1), n.gradfindif(g[1], 2), n.gradfindif(g[2], 2)
+    assert rel_l2(o.calc_m2v_mem(phi), xx * yy - xy * xy + xx * zz - xz * xz + yy * zz - yz * yz) < 1e-13
+    # kernelcomp: Gaussian on the full grid, normalised so that the k = 0 mode is 1; convcomp keeps constants
+    K = o.kernelcomp(p.kth).reshape(n.shape)
+    assert abs(K[0, 0, 0] - 1.0) < 1e-14
+    assert rel_l2(K[:, :, : p.Nx // 2 + 1], n.alpt_kernel(p.kth)) < 1e-14
+    assert rel_l2(o.convcomp(np.full(p.N, 3.5), p.kth), np.full(p.N, 3.5)) < 1e-14
+    assert rel_l2(o.convcomp(q, p.kth), n.c2r(n.r2c(q) * n.alpt_kernel(p.kth))) < 1e-13
+    # theta2velcomp is theta2vel component by component
+    v = o.theta2vel(q)
+    for comp in (1, 2, 3):
+        assert rel_l2(o.theta2velcomp(q, comp), v[comp - 1]) < 1e-14
+    # cellboundcomp: mean with the (i-1, j-1, k-1) neighbour, periodic
+    a = np.arange(p.N, dtype=np.float64).reshape(n.shape)
+    assert np.array_equal(o.cellboundcomp(a).reshape(n.shape), 0.5 * (a + np.roll(a, (1, 1, 1), (0, 1, 2))))
+    # the whole displacement, two independent restatements
+    for ours, theirs in zip(n.alpt_displacement(q), o.alpt_displacement(q)):
+        assert rel_l2(ours, theirs) < 1e-13
+
+
+def test_alpt_displacement_has_the_reference_sign_and_zeldovich_limit():
+    """Finding M11: Lag2Eul_non_zeldovich feeds +D1 delta (minus the divergence) to the velocity kernel where
+    Lag2Eul_zeldovich feeds -D1 delta (Lag2Eul.cc:88 vs 199-200, 212-226), so for small delta the ALPT displacement
+    is MINUS the Zel'dovich one (up to the cell-boundary average).  Restated as is."""
+    c = Case(Nx=8, likelihood=1, rsd_model=0, sfmodel=2)
+    o, p = c.oracle, c.p
+    q = 1e-4 * c.q0
+    za = o.theta2vel(-p.D1 * q.ravel())
+    alpt = o.alpt_displacement(q)
+    for a, z in zip(alpt, za):
+        assert rel_l2(a, -o.cellboundcomp(z)) < 1e-3
