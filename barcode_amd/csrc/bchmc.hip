@@ -1527,6 +1527,46 @@ int bchmc_chain_accept(bchmc_handle *h, int accepted) {
   return BCHMC_OK;
 }
 
+int bchmc_measure_spectrum(bchmc_handle *h, const double *signal, uint64_t n_bin, double *kmode, double *power) {
+  if (!h || !kmode || !power || n_bin == 0 || n_bin > 2048) return BCHMC_ERR_ARG;
+  ENTER(h);
+  const void *xk = nullptr;
+  if (signal) {
+    HIPCHK(hipMemcpyAsync(h->dstage, signal, h->g.N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    CHK(DISPATCH(h, r2c_state(h, h->dstage, h->ioq, h->tC)));
+    xk = h->tC;
+  } else {
+    if (!h->have_cq) return h->fail(BCHMC_ERR_STATE, "no chain state: call bchmc_chain_set_state first");
+    xk = h->cq;
+  }
+  double *bins = nullptr;
+  CHK(dev_alloc(h, &bins, 3 * (size_t)n_bin));  // zero-filled
+  const Geo &g = h->g;
+  const double knyq = g.kfac * (double)(g.n / 2);
+  const double kmax = std::sqrt(knyq * knyq + knyq * knyq + knyq * knyq);
+  const double dk = kmax / (double)n_bin;
+  const int grid = std::min(nblk_stride(g.Nhp), 512);
+  if (h->f32)
+    k_spectrum<float><<<grid, 256, 3 * n_bin * sizeof(double), h->stream>>>(
+        g, reinterpret_cast<const float2 *>(xk), (int)n_bin, dk, bins);
+  else
+    k_spectrum<double><<<grid, 256, 3 * n_bin * sizeof(double), h->stream>>>(
+        g, reinterpret_cast<const double2 *>(xk), (int)n_bin, dk, bins);
+  std::vector<double> hb(3 * n_bin);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(hb.data(), bins, hb.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  (void)hipFree(bins);
+  if (e != hipSuccess) return h->fail(BCHMC_ERR_HIP, "measure_spectrum: %s", hipGetErrorString(e));
+  const double N = (double)g.N, NORM = g.L * g.L * g.L / N / N;  // FOURIER_DEF_2, field_statistics.cpp:73-75
+  for (uint64_t l = 0; l < n_bin; l++) {
+    const double cnt = hb[2 * n_bin + l];
+    kmode[l] = cnt > 0. ? hb[l] / cnt : 0.;
+    power[l] = cnt > 0. ? hb[n_bin + l] / cnt * NORM : 0.;
+  }
+  return BCHMC_OK;
+}
+
 int bchmc_philox_kat(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
   if (!ctr || !key || !out) return BCHMC_ERR_ARG;
   uint4 *d = nullptr;

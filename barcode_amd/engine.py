@@ -61,7 +61,7 @@ EXPORTS = ("bchmc_create", "bchmc_destroy", "bchmc_strerror", "bchmc_last_error"
            "bchmc_profile", "bchmc_profile_read", "bchmc_kernel_name",
            "bchmc_chain_set_state", "bchmc_chain_get_state", "bchmc_chain_set_momenta", "bchmc_chain_get_momenta",
            "bchmc_chain_draw_momenta", "bchmc_chain_attempt", "bchmc_chain_get_proposal", "bchmc_chain_accept",
-           "bchmc_philox_kat")
+           "bchmc_measure_spectrum", "bchmc_philox_kat")
 
 
 def load():
@@ -106,6 +106,7 @@ def load():
     lib.bchmc_chain_attempt.argtypes = [vp, C.c_double, u64, dp, dp, C.POINTER(u64)]
     lib.bchmc_chain_get_proposal.argtypes = [vp, dp, dp]
     lib.bchmc_chain_accept.argtypes = [vp, C.c_int]
+    lib.bchmc_measure_spectrum.argtypes = [vp, dp, C.c_uint64, dp, dp]
     lib.bchmc_philox_kat.argtypes = [C.POINTER(C.c_uint32)] * 3
     _lib = lib
     return lib
@@ -281,6 +282,14 @@ class Engine:
 
     def chain_accept(self, accepted):
         self._chk(self.lib.bchmc_chain_accept(self.h, int(bool(accepted))))
+
+    def measure_spectrum(self, signal=None, n_bin=200):
+        """measure_spectrum (field_statistics.cpp:20-90) of a host field, or of the resident chain state when
+        ``signal`` is None (nothing but 2 x n_bin doubles crosses PCIe).  Returns (kmode, power)."""
+        kmode, power = np.empty(n_bin), np.empty(n_bin)
+        sig = None if signal is None else _p(self._in(signal))
+        self._chk(self.lib.bchmc_measure_spectrum(self.h, sig, int(n_bin), _p(kmode), _p(power)))
+        return kmode, power
 
     # ---- measurement ---------------------------------------------------------------------------
     def profile(self, enable):

@@ -108,6 +108,12 @@ def delta_Hamiltonian(hd, signali, momentai, signalf, momentaf):
     return n.dH
 
 
+def measure_spectrum(hd, signal=None, N_bin=200):
+    """field_statistics.cpp:20-90 -> (kmode, power).  ``signal`` None = the resident chain state (what
+    barcoderunner.cc:530-533 measures after every sample, without moving the field off the device)."""
+    return hd.engine.measure_spectrum(signal, N_bin)
+
+
 def HamiltonianMC(hd, uniform, seed=1, itmax=2000, ring=None, group=None, momenta=None):
     """One sample of the reference's HamiltonianMC loop (HMC.cc:431-511) on the device-resident chain:
     repeat { draw momenta; draw (Neps, epsilon); trajectory; dH; Metropolis test } until accepted.

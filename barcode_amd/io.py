@@ -51,3 +51,17 @@ def performance_log_row(rec):
         else:
             out.append("%g" % float(v))
     return "\t".join(out) + "\n"
+
+
+def dump_measured_spec(kmode, power, fname):
+    """``dump_measured_spec`` / ``dump_ps_it`` (IOfunctions.cc:20-34, 37-82): one ``k   P(k)`` line per bin with
+    ``k > 0`` and ``P > 0``, C++ default stream formatting (6 significant digits).  ``dump_ps_it`` names the file
+    ``<dir>powSpecit<iGibbs>.dat`` (``power_spectrum_filename``)."""
+    with open(fname, "w") as f:
+        for x, y in zip(np.asarray(kmode).ravel(), np.asarray(power).ravel()):
+            if y > 0.0 and x > 0.0:
+                f.write("%g   %g\n" % (x, y))
+
+
+def power_spectrum_filename(directory, iGibbs):
+    return os.path.join(directory, "powSpecit%d.dat" % int(iGibbs)) if directory else "powSpecit%d.dat" % int(iGibbs)

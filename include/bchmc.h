@@ -152,6 +152,11 @@ int bchmc_chain_draw_momenta(bchmc_handle *h, uint64_t seed, uint64_t attempt);
 int bchmc_chain_attempt(bchmc_handle *h, double eps, uint64_t neps, double *dH, double terms[6], uint64_t *steps_done);
 int bchmc_chain_get_proposal(bchmc_handle *h, double *q1, double *p1);
 int bchmc_chain_accept(bchmc_handle *h, int accepted);         /* accepted: q := proposal (HMC.cc:497-498) */
+/* measure_spectrum (barlib/src/field_statistics.cpp:20-90; callers barcoderunner.cc:328,532 -> dump_ps_it): binned
+ * power spectrum of a field, n_bin bins of width |k|_max / n_bin.  `signal` = N host doubles, or NULL for the
+ * resident chain state (no transform and no field transfer: its R2C is what the chain keeps).  kmode / power:
+ * n_bin doubles each; empty bins stay 0 like upstream. */
+int bchmc_measure_spectrum(bchmc_handle *h, const double *signal, uint64_t n_bin, double *kmode, double *power);
 int bchmc_philox_kat(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]); /* known-answer hook for tests */
 
 /* ---- measurement hooks (bench.py): per-kernel-class HIP-event timing on the engine's stream ---- */

@@ -1109,6 +1109,47 @@ int orc_alpt_displacement(orc_hamil *h, const double *in, double *psix, double *
   return ORC_OK;
 }
 
+/* ================================================================================================
+ * f-4: measure_spectrum, field_statistics.cpp:20-90.  The reference transforms the real field with a full
+ * complex FFT and visits all N1 N2 N3 modes; F(-k) = conj F(k), so the half-complex transform holds every value.
+ * ============================================================================================== */
+int orc_measure_spectrum(orc_hamil *h, const double *signal, double *kmode, double *power, uint64_t N_bin) {
+  const unsigned N1 = h->N1, N2 = h->N2, N3 = h->N3, N3half = N3 / 2 + 1;
+  if (N_bin == 0) return ORC_ERR_ARG;
+  uint64_t *nmode = (uint64_t *)calloc(N_bin, sizeof(uint64_t));
+  for (uint64_t l = 0; l < N_bin; l++) kmode[l] = power[l] = 0.;
+  double *C = dalloc(2 * h->Nhalf), *R = dalloc(h->N);
+  copyArray(signal, R, h->N);
+  orc_fft_r2c_3d(N1, N2, N3, R, C);
+  const double kmax = sqrt(k_squared_full(h, N1 / 2, N2 / 2, N3 / 2));
+  const double dk = kmax / (double)N_bin;
+  for (unsigned i = 0; i < N1; i++)
+    for (unsigned j = 0; j < N2; j++)
+      for (unsigned k = 0; k < N3; k++) {
+        double ktot = sqrt(k_squared_full(h, i, j, k));
+        uint64_t nbin = (uint64_t)(ktot / dk);
+        if (nbin < N_bin) {
+          size_t ix;
+          if (k < N3half)
+            ix = k + (size_t)N3half * (j + (size_t)N2 * i);
+          else /* conjugate partner */
+            ix = (N3 - k) + (size_t)N3half * (((N2 - j) % N2) + (size_t)N2 * ((N1 - i) % N1));
+          double akl = C[2 * ix], bkl = C[2 * ix + 1];
+          kmode[nbin] += 1 * ktot;
+          power[nbin] += (akl * akl + bkl * bkl);
+          nmode[nbin] += 1;
+        }
+      }
+  const double NORM = h->L1 * h->L2 * h->L3 / (double)h->N / (double)h->N; /* FOURIER_DEF_2 */
+  for (uint64_t l = 0; l < N_bin; l++)
+    if (nmode[l] > 0) {
+      kmode[l] = kmode[l] / (double)nmode[l];
+      power[l] = power[l] / (double)nmode[l] * NORM;
+    }
+  free(nmode); free(C); free(R);
+  return ORC_OK;
+}
+
 /* *_likelihood_grad_f_delta_x_comp: gaussian_independent.cpp:43-50 (gradfft), poissonian.cpp:37-42 (gradfindif),
  * lognormal_independent.cpp:71-91 (gradfindif of log(rho_c (1 + max(delta, delta_min)))) */
 static int grad_f_delta_x_comp(orc_hamil *h, const double *deltaX, double *out, unsigned comp) {

@@ -102,6 +102,9 @@ int orc_theta2velcomp(orc_hamil *h, const double *delta, double *vei, int comp);
 int orc_cellboundcomp(orc_hamil *h, double *vi);                                   /* massFunctions.cc:588-658 */
 int orc_alpt_displacement(orc_hamil *h, const double *in, double *psix, double *psiy, double *psiz);
 
+/* f-4: field_statistics.cpp:20-90 (FOURIER_DEF_2) */
+int orc_measure_spectrum(orc_hamil *h, const double *signal, double *kmode, double *power, uint64_t N_bin);
+
 double orc_fgrow(double a, double OM, double OL, int term);    /* cosmo.cc:182-217 */
 double orc_c_pecvel(double a, double OM, double OL, int term); /* cosmo.cc:220-235 */
 

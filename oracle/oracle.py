@@ -102,6 +102,7 @@ def _lib(omp):
             "orc_theta2velcomp": [vp, dp, dp, C.c_int],
             "orc_cellboundcomp": [vp, dp],
             "orc_alpt_displacement": [vp, dp, dp, dp, dp],
+            "orc_measure_spectrum": [vp, dp, dp, dp, C.c_uint64],
         }.items():
             getattr(lib, name).argtypes = args
             getattr(lib, name).restype = C.c_int
@@ -232,6 +233,12 @@ class Oracle:
         px, py, pz = self._new(), self._new(), self._new()
         self._chk(self.lib.orc_alpt_displacement(self.h, _p(self._in(delta)), _p(px), _p(py), _p(pz)))
         return px, py, pz
+
+    def measure_spectrum(self, signal, N_bin=200):
+        """field_statistics.cpp:20-90 -> (kmode, power), both N_bin long."""
+        kmode, power = np.empty(N_bin), np.empty(N_bin)
+        self._chk(self.lib.orc_measure_spectrum(self.h, _p(self._in(signal)), _p(kmode), _p(power), int(N_bin)))
+        return kmode, power
 
     def Lag2Eul(self, delta, rsd=None):
         out, px, py, pz = (self._new() for _ in range(4))

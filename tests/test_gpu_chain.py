@@ -134,3 +134,23 @@ def test_hamiltonian_mc_loop_on_resident_chain():
         q1, _ = hd.engine.chain_get_proposal() if False else (hd.engine.chain_get_state(), None)
         assert rel_l2(q1, c.q0) > 0  # the state moved
     hd.engine.close()
+
+
+@pytest.mark.parametrize("nx,precision", [(16, 0), (12, 0), (16, 1)])
+def test_measure_spectrum_host_field_and_resident_state(nx, precision):
+    """bchmc_measure_spectrum == measure_spectrum (field_statistics.cpp:20-90) for a host array and for the chain
+    state kept on the device (whose R2C is already resident: no transform, no field transfer)."""
+    c = Case(Nx=nx)
+    e = c.engine(precision=precision)
+    tol = 1e-12 if precision == 0 else 2e-5
+    for nb in (20, 200):
+        kmo, pwo = c.oracle.measure_spectrum(c.q0, nb)
+        km, pw = e.measure_spectrum(c.q0, nb)
+        atol = tol * pwo.max()  # the k = 0 bin of a zero-mean field is round-off on both sides
+        assert np.allclose(km, kmo, rtol=1e-13, atol=0) and np.allclose(pw, pwo, rtol=tol, atol=atol)
+        e.chain_set_state(c.q0)
+        km2, pw2 = e.measure_spectrum(None, nb)
+        assert np.allclose(km2, kmo, rtol=1e-13, atol=0) and np.allclose(pw2, pwo, rtol=tol, atol=atol)
+    with pytest.raises(Exception):
+        e.measure_spectrum(c.q0, 0)
+    e.close()

@@ -36,3 +36,12 @@ def test_performance_log_schema():
                psi_prior_i=1234567.0, psi_prior_f=1.0, psi_likeli_i=2.0, psi_likeli_f=3.0, H_kin_i=4.0, H_kin_f=5.0)
     row = bio.performance_log_row(rec).rstrip("\n").split("\t")
     assert row[:4] == ["1", "0.00123457", "5", "-1.5"] and row[8] == "1.23457e+06" and len(row) == 14
+
+
+def test_dump_measured_spec_format(tmp_path):
+    """IOfunctions.cc:29-31 / 75-80: bins with k > 0 and P > 0 only, `k   P`, 6 significant digits."""
+    from barcode_amd.io import dump_measured_spec, power_spectrum_filename
+    fn = power_spectrum_filename(str(tmp_path), 12)
+    assert fn.endswith("powSpecit12.dat")
+    dump_measured_spec([0.0, 0.0314159265, 0.25, 1.5], [5.0, 1234.56789, 0.0, 1e-5], fn)
+    assert open(fn).read() == "0.0314159   1234.57\n1.5   1e-05\n"

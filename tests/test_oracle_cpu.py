@@ -209,3 +209,24 @@ def test_alpt_displacement_has_the_reference_sign_and_zeldovich_limit():
     alpt = o.alpt_displacement(q)
     for a, z in zip(alpt, za):
         assert rel_l2(a, -o.cellboundcomp(z)) < 1e-3
+
+
+def test_measure_spectrum_against_full_grid_numpy():
+    """field_statistics.cpp:20-90 restated on the half-complex transform == the literal full-grid loop in numpy."""
+    c = Case(Nx=8)
+    n, L, nb = 8, c.p.L, 20
+    km, pw = c.oracle.measure_spectrum(c.q0, nb)
+    F = np.fft.fftn(c.q0.reshape(n, n, n))
+    i = np.arange(n)
+    k1 = np.where(i <= n // 2, 2 * np.pi / L * i, -2 * np.pi / L * (n - i))
+    kt = np.sqrt(k1[:, None, None] ** 2 + k1[None, :, None] ** 2 + k1[None, None, :] ** 2)
+    dk = np.sqrt(3.0) * 2 * np.pi / L * (n // 2) / nb
+    b = (kt / dk).astype(np.int64).ravel()
+    ok = b < nb
+    cnt = np.bincount(b[ok], minlength=nb)
+    ks = np.bincount(b[ok], weights=kt.ravel()[ok], minlength=nb)
+    ps = np.bincount(b[ok], weights=(np.abs(F) ** 2).ravel()[ok], minlength=nb)
+    has = cnt > 0
+    assert np.allclose(km[has], ks[has] / cnt[has], rtol=1e-14) and np.all(km[~has] == 0)
+    assert np.allclose(pw[has], ps[has] / cnt[has] * L ** 3 / n ** 6, rtol=1e-13) and np.all(pw[~has] == 0)
+    assert cnt.sum() == n ** 3 - 1  # only the |k|max corner mode falls outside (field_statistics.cpp:49-51)
