@@ -87,11 +87,13 @@ struct bchmc_handle {
   bool hull_exact = false;  // no cell of the (2 reach + 1)^3 cube outside the hull can pass r/h <= 2
   // tile-sorted particle-mesh path
   bool tiled = false;
+  bool sort_direct = false;  // one-pass tile binning into fixed slots (two-pass sort as overflow fallback)
   bool disp_alpt = false;    // Ck holds an ALPT displacement: forward_rest applies cellboundcomp after the C2R
   double alpt_wtot = 0.;     // kernelcomp's normalisation (sum of the real-space kernel), computed on first use
   bool std81 = false;  // standard 81-cell hull on 8 x 8 x 16 tiles with halo 2: fully unrolled scatter/gather kernels
   TilePar tp{};
-  int *t_cnt = nullptr, *t_off = nullptr, *t_woff = nullptr;  // ntiles, ntiles+1, ntiles+1
+  int *t_cnt = nullptr, *t_off = nullptr, *t_woff = nullptr;  // 2 * ntiles + 1 (direct counts, fallback counts, overflow flag), ntiles, ntiles+1
+  int *t_end = nullptr;                                        // ntiles
   int2 *t_rank = nullptr;                                      // N
   void *sx = nullptr, *sy = nullptr, *sz = nullptr;            // N each: sorted positions
   int *sidx = nullptr;                                         // N: original index | flags
@@ -306,6 +308,44 @@ int check_inputs(bchmc_handle *h) {
   return BCHMC_OK;
 }
 
+// One-pass tile binning: if a tile overflowed its record slots since the last check (sticky flag set by
+// k_bin<DIRECT>; that step fell back to the two-pass sort), double the slots -- or give the one-pass path up when
+// they would no longer be addressable / allocatable.  Called at the start of every trajectory and forward model.
+int grow_sort_slots(bchmc_handle *h) {
+  if (!h->tiled || !h->sort_direct) return BCHMC_OK;
+  int *sticky = h->t_cnt + 2 * (size_t)h->tp.ntiles + 1;
+  int seen = 0;
+  HIPCHK(hipMemcpyAsync(&seen, sticky, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (!seen) return BCHMC_OK;
+  HIPCHK(hipMemsetAsync(sticky, 0, sizeof(int), h->stream));
+  const long long cap = 2ll * h->tp.cap;
+  h->sorted_valid = false;
+  if (cap * h->tp.ntiles >= (1ll << 31)) {
+    h->sort_direct = false;
+    return BCHMC_OK;
+  }
+  // never fewer than N records: the two-pass sort packs all particles
+  const size_t nrec = std::max<size_t>((size_t)h->g.N, (size_t)cap * h->tp.ntiles);
+  void *nx = nullptr, *ny = nullptr, *nz = nullptr, *ni = nullptr;
+  const bool ok = hipMalloc(&nx, nrec * h->esz) == hipSuccess && hipMalloc(&ny, nrec * h->esz) == hipSuccess &&
+                  hipMalloc(&nz, nrec * h->esz) == hipSuccess && hipMalloc(&ni, nrec * sizeof(int)) == hipSuccess;
+  if (!ok) {
+    for (void *p : {nx, ny, nz, ni})
+      if (p) (void)hipFree(p);
+    (void)hipGetLastError();
+    h->sort_direct = false;  // the existing arrays hold >= N records: enough for the two-pass sort
+    return BCHMC_OK;
+  }
+  for (void *p : {h->sx, h->sy, h->sz, (void *)h->sidx}) (void)hipFree(p);
+  h->sx = nx;
+  h->sy = ny;
+  h->sz = nz;
+  h->sidx = (int *)ni;
+  h->tp.cap = (int)cap;
+  return BCHMC_OK;
+}
+
 // Sum kRedBlocks device partials on the host (synchronises the stream).
 int host_sum(bchmc_handle *h, const double *d_part, double *out) {
   HIPCHK(hipMemcpyAsync(h->h_part, d_part, kRedBlocks * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -467,11 +507,22 @@ struct Pipe {
     if (h->c.mk == 3 && h->tiled) {
       // counting sort of the particles by the Eulerian tile of their home cell
       ProfScope ps(h, BCHMC_K_SORT);
-      HIPCHK(hipMemsetAsync(h->t_cnt, 0, h->tp.ntiles * sizeof(int), h->stream));
-      k_bin<T><<<nblk_full(h->g.N), 256, 0, h->stream>>>(h->g, pp, sp, h->tp, R(h->psi), h->t_cnt, h->t_rank, R(h->V));
-      k_scan_tiles<<<1, 1024, 0, h->stream>>>(h->tp, h->t_cnt, h->t_off, h->t_woff);
-      k_reorder<T><<<nblk_full(h->g.N), 256, 0, h->stream>>>(h->g, pp, R(h->psi), h->t_rank, h->t_off, R(h->sx),
-                                                             R(h->sy), R(h->sz), h->sidx);
+      // one-pass binning into fixed slots per tile; the two-pass kernels run only if a tile overflowed
+      const int nt = h->tp.ntiles, nbricks = nblk_full(h->g.N);
+      int *cnt1 = h->t_cnt, *cnt2 = h->t_cnt + nt, *ovf = h->t_cnt + 2 * nt;  // ovf[1] is sticky, see grow_sort_slots
+      HIPCHK(hipMemsetAsync(h->t_cnt, 0, (2 * (size_t)nt + 1) * sizeof(int), h->stream));
+      const int fb_grid = h->sort_direct ? std::min(nbricks, 4096) : nbricks;
+      if (h->sort_direct) {
+        k_bin<T, true><<<nbricks, 256, 0, h->stream>>>(h->g, pp, sp, h->tp, nbricks, R(h->psi), cnt1, ovf, h->t_rank,
+                                                       R(h->sx), R(h->sy), R(h->sz), h->sidx, R(h->V));
+      } else {
+        HIPCHK(hipMemsetAsync(ovf, 1, 1, h->stream));  // non-zero flag: two-pass sort only
+      }
+      k_bin<T, false><<<fb_grid, 256, 0, h->stream>>>(h->g, pp, sp, h->tp, nbricks, R(h->psi), cnt2, ovf, h->t_rank,
+                                                      R(h->sx), R(h->sy), R(h->sz), h->sidx, R(h->V));
+      k_scan_tiles<<<1, 1024, 0, h->stream>>>(h->tp, cnt1, cnt2, ovf, h->t_off, h->t_end, h->t_woff);
+      k_reorder<T><<<fb_grid, 256, 0, h->stream>>>(h->g, pp, nbricks, R(h->psi), h->t_rank, h->t_off, ovf, R(h->sx),
+                                                   R(h->sy), R(h->sz), h->sidx);
       HIPCHK(hipGetLastError());
       h->sorted_valid = true;
     }
@@ -486,11 +537,11 @@ struct Pipe {
         const int reorder = (h->tp.chunk != 2048) ? 0 : (sb ? std::min(std::max(atoi(sb), 0), 2) : 2);
         if (h->std81)
           k_scatter_tile81<T, 12, 20><<<grid, 256, tile_lds(h, 0, sizeof(double)), h->stream>>>(
-              h->g, sp, h->tp, reorder, R(h->sx), R(h->sy), R(h->sz), h->sidx, h->t_off, h->t_woff, R(h->rho));
+              h->g, sp, h->tp, reorder, R(h->sx), R(h->sy), R(h->sz), h->sidx, h->t_off, h->t_end, h->t_woff, R(h->rho));
         else
           k_scatter_tile<T><<<grid, 256, tile_lds(h, ncol, sizeof(double)), h->stream>>>(
-              h->g, sp, h->tp, h->hull, ncol, reorder, R(h->sx), R(h->sy), R(h->sz), h->sidx, h->t_off, h->t_woff,
-              R(h->rho));
+              h->g, sp, h->tp, h->hull, ncol, reorder, R(h->sx), R(h->sy), R(h->sz), h->sidx, h->t_off, h->t_end,
+              h->t_woff, R(h->rho));
       } else if (h->c.mk == 3) {
         k_scatter_sph<T><<<nblk_full(h->g.N), 256, 0, h->stream>>>(h->g, pp, sp, R(h->psi), R(h->rho));
       } else if (h->c.mk >= 0 && h->c.mk <= 2) {
@@ -592,11 +643,11 @@ struct Pipe {
         const int grid = h->tp.ntiles + (int)(N / h->tp.chunk) + 1;
         if (h->std81)
           k_gather_tile81<T, 12, 20><<<grid, 256, tile_lds(h, 0, sizeof(T)), h->stream>>>(
-              h->g, hp, h->tp, h->last_rsd, R(h->sx), R(h->sy), R(h->sz), h->sidx, h->t_off, h->t_woff, R(h->plike),
+              h->g, hp, h->tp, h->last_rsd, R(h->sx), R(h->sy), R(h->sz), h->sidx, h->t_off, h->t_end, h->t_woff, R(h->plike),
               R(h->V));
         else
           k_gather_tile<T><<<grid, 256, tile_lds(h, hp.ncol, sizeof(T)), h->stream>>>(
-              h->g, hp, h->tp, h->last_rsd, R(h->sx), R(h->sy), R(h->sz), h->sidx, h->t_off, h->t_woff, R(h->plike),
+              h->g, hp, h->tp, h->last_rsd, R(h->sx), R(h->sy), R(h->sz), h->sidx, h->t_off, h->t_end, h->t_woff, R(h->plike),
               R(h->V));
       } else {
         k_gather_sph<T><<<nblk_full(N), 256, hp.ncol * sizeof(int4), h->stream>>>(h->g, make_pos(h, h->last_rsd), hp,
@@ -710,6 +761,7 @@ struct Pipe {
 
   // Hamiltonian_EoM (HMC.cc:275-365) on the k-space state already in (qk, pk).
   static int trajectory(bchmc_handle *h, double eps, uint64_t neps, const Tap *tap) {
+    CHK(grow_sort_slots(h));
     if (neps + 1 > h->guard_cap) {
       if (h->guard) (void)hipFree(h->guard);
       h->guard = nullptr;
@@ -982,6 +1034,7 @@ struct Pipe {
   }
 
   static int forward(bchmc_handle *h, const double *d_q, int rsd) {
+    CHK(grow_sort_slots(h));
     CHK(r2c_state(h, d_q, h->ioq, h->qk));
     CHK(displacement(h, 1., rsd));
     return forward_rest(h, rsd);
@@ -1276,14 +1329,28 @@ int bchmc_create(const bchmc_config *cfg, bchmc_handle **out) {
             if (zw < 0 || c.z != -zw || c.w != zw) is81 = false;
           }
           h->std81 = is81 && !env_on("BCHMC_NO_UNROLL");
-          CHK(dev_alloc(h, &h->t_cnt, (size_t)tp.ntiles));
-          CHK(dev_alloc(h, &h->t_off, (size_t)tp.ntiles + 1));
+          // One-pass binning: `cap` record slots per tile = 8x the mean occupancy to start with (the 288 GB of HBM
+          // pay for a whole pass over the particles: 3.8 GB of slots at 256^3 fp64), doubled by grow_sort_slots
+          // whenever a tile overflowed (the two-pass sort covers that step); BCHMC_SORT_CAP overrides
+          // (a tiny value forces the two-pass fallback in tests), 0 disables the one-pass path.
+          const long long mean_occ = (long long)tp.tx * tp.ty * tp.tz;
+          long long cap = std::max<long long>(8 * mean_occ, 64);
+          if (const char *ev = std::getenv("BCHMC_SORT_CAP")) cap = atoll(ev);
+          size_t nrec = N;
+          h->sort_direct = cap > 0 && cap * tp.ntiles < (1ll << 31);
+          if (h->sort_direct) {
+            tp.cap = (int)cap;
+            nrec = std::max<size_t>(N, (size_t)cap * tp.ntiles);
+          }
+          CHK(dev_alloc(h, &h->t_cnt, 2 * (size_t)tp.ntiles + 2));
+          CHK(dev_alloc(h, &h->t_off, (size_t)tp.ntiles));
+          CHK(dev_alloc(h, &h->t_end, (size_t)tp.ntiles));
           CHK(dev_alloc(h, &h->t_woff, (size_t)tp.ntiles + 1));
           CHK(dev_alloc(h, &h->t_rank, N));
-          CHK(dev_alloc_bytes(h, &h->sx, N * e));
-          CHK(dev_alloc_bytes(h, &h->sy, N * e));
-          CHK(dev_alloc_bytes(h, &h->sz, N * e));
-          CHK(dev_alloc(h, &h->sidx, N));
+          CHK(dev_alloc_bytes(h, &h->sx, nrec * e));
+          CHK(dev_alloc_bytes(h, &h->sy, nrec * e));
+          CHK(dev_alloc_bytes(h, &h->sz, nrec * e));
+          CHK(dev_alloc(h, &h->sidx, nrec));
         }
       }
     }
@@ -1307,7 +1374,7 @@ void bchmc_destroy(bchmc_handle *h) {
   void *ptrs[] = {h->work,  h->wS,       h->wM,    h->qk,    h->pk,   h->gk,     h->Ck,         h->tC,   h->psi,
                   h->V,     h->rho,      h->plike, h->ioq,   h->iop,  h->gprior, h->glike,      h->conv, h->convF,
                   h->dstage, h->cq, h->cp, h->qk2, h->pk2, h->part6, h->rho_part, h->partA, h->guard, h->stop, h->steps_done, h->hull,  h->t_cnt, h->t_off,
-                  h->t_woff, h->t_rank,  h->sx,    h->sy,    h->sz,   h->sidx};
+                  h->t_woff, h->t_end, h->t_rank,  h->sx,    h->sy,    h->sz,   h->sidx};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   for (int f = 0; f < 6; f++)

@@ -1032,6 +1032,7 @@ struct TilePar {
   int R;              // halo = farthest stencil offset
   int lx, ly, lz;     // LDS tile shape = t + 2R
   int chunk;          // max particles per work item
+  int cap;            // record slots reserved per tile by the one-pass binning (k_bin<DIRECT>)
 };
 
 constexpr int kSortFlagNoScatter = 1 << 30;  // record flag: particle fails getDensity_SPH's domain test
@@ -1077,18 +1078,17 @@ __device__ __forceinline__ int tile_of_wrapped(const TilePar &tp, int cx, int cy
 
 // Workgroup -> particles.  When 16 divides n a workgroup takes a 4 x 4 x 16 brick of the Lagrangian lattice
 // (neighbours in space: few distinct tiles per workgroup, 128-byte rows of psi); otherwise 256 consecutive ones.
-__device__ __forceinline__ long long brick_particle(const Geo &g, int &i, int &j, int &k) {
+__device__ __forceinline__ long long brick_particle(const Geo &g, int b, int &i, int &j, int &k) {
   const int n = g.n, tid = threadIdx.x;
   if ((n & 15) == 0) {
     const int nbz = n >> 4, nby = n >> 2;
-    const int b = blockIdx.x;
     const int bk = b % nbz, bj = (b / nbz) % nby, bi = b / (nbz * nby);
     i = bi * 4 + (tid >> 6);
     j = bj * 4 + ((tid >> 4) & 3);
     k = bk * 16 + (tid & 15);
     return k + (long long)n * (j + (long long)n * i);
   }
-  const long long p = blockIdx.x * (long long)blockDim.x + tid;
+  const long long p = b * (long long)blockDim.x + tid;
   k = (int)(p % n);
   const long long ij = p / n;
   j = (int)(ij % n);
@@ -1096,55 +1096,83 @@ __device__ __forceinline__ long long brick_particle(const Geo &g, int &i, int &j
   return p;
 }
 
-// Pass 1: tile id and arrival rank of every particle.  The workgroup first counts its particles per tile in
-// an LDS hash table, then reserves one contiguous rank range per distinct tile with a single global atomic
-// (a handful per workgroup instead of one returning atomic per particle on ~n^3/2048 hot counters).
-// Particles with a non-finite position are left out (tile -1); the gather gives them V = 0.
-template <typename T>
+// Binning.  The workgroup first counts its particles per tile in an LDS hash table, then reserves one contiguous
+// rank range per distinct tile with a single global atomic (a handful per workgroup instead of one returning
+// atomic per particle on ~n^3/2048 hot counters).  Particles with a non-finite position are left out; the gather
+// gives them V = 0.
+//   DIRECT = true  (one-pass sort): every tile owns `tp.cap` record slots, the particle's record (position, index |
+//                  flag) goes straight to slot tile * cap + rank.  A rank >= cap raises *ovf and the record is dropped:
+//                  the two-pass kernels below then redo the sort from scratch (they return at once otherwise).
+//   DIRECT = false (two-pass fallback, pass 1): tile id and arrival rank of every particle to tile_rank.
+template <typename T, bool DIRECT>
 __global__ void __launch_bounds__(256)
-k_bin(Geo g, PosPar pp, SphPar sp, TilePar tp, const T *__restrict__ psi, int *__restrict__ cnt,
-      int2 *__restrict__ tile_rank, T *__restrict__ V) {
+k_bin(Geo g, PosPar pp, SphPar sp, TilePar tp, int nbricks, const T *__restrict__ psi, int *__restrict__ cnt,
+      int *__restrict__ ovf,
+      int2 *__restrict__ tile_rank, T *__restrict__ sx, T *__restrict__ sy, T *__restrict__ sz, int *__restrict__ sidx,
+      T *__restrict__ V) {
   constexpr int kSlots = 512;
   __shared__ int hkey[kSlots], hcnt[kSlots], hbase[kSlots];
-  for (int s = threadIdx.x; s < kSlots; s += blockDim.x) {
-    hkey[s] = 0;
-    hcnt[s] = 0;
-  }
-  __syncthreads();
-  int i, j, k;
-  const long long p = brick_particle(g, i, j, k);
-  const bool live = p < g.N;
-  int t = -1, slot = 0, local = 0, flag = 0;
-  if (live) {
-    T x, y, z;
-    particle_pos<T>(pp, i, j, k, psi[p], psi[p + g.N], psi[p + 2 * g.N], x, y, z);
-    if (pos_ok(g, x, y, z)) {
-      const HomeCell<T> hc = make_home<T>(g);
-      t = tile_of_wrapped(tp, wrap_cell(home_cell_i(hc, x), g.n), wrap_cell(home_cell_i(hc, y), g.n),
-                          wrap_cell(home_cell_i(hc, z), g.n));
-      flag = in_domain(g, sp, x, y, z) ? 0 : kSortFlagNoScatter;
-      slot = (int)(((unsigned)t * 2654435761u) >> 23) & (kSlots - 1);
-      for (;;) {
-        const int old = atomicCAS(&hkey[slot], 0, t + 1);
-        if (old == 0 || old == t + 1) break;
-        slot = (slot + 1) & (kSlots - 1);
-      }
-      local = atomicAdd(&hcnt[slot], 1);
-    } else {
-      V[p] = T(0);
-      V[p + g.N] = T(0);
-      V[p + 2 * g.N] = T(0);
+  if (!DIRECT && !*ovf) return;
+  // DIRECT: one brick per workgroup; fallback: a small grid strides over the bricks (it usually returns above)
+  for (int brick = blockIdx.x; brick < nbricks; brick += gridDim.x) {
+    for (int s = threadIdx.x; s < kSlots; s += blockDim.x) {
+      hkey[s] = 0;
+      hcnt[s] = 0;
     }
+    __syncthreads();
+    int i, j, k;
+    const long long p = brick_particle(g, brick, i, j, k);
+    const bool live = p < g.N;
+    int t = -1, slot = 0, local = 0, flag = 0;
+    T x = T(0), y = T(0), z = T(0);
+    if (live) {
+      particle_pos<T>(pp, i, j, k, psi[p], psi[p + g.N], psi[p + 2 * g.N], x, y, z);
+      if (pos_ok(g, x, y, z)) {
+        const HomeCell<T> hc = make_home<T>(g);
+        t = tile_of_wrapped(tp, wrap_cell(home_cell_i(hc, x), g.n), wrap_cell(home_cell_i(hc, y), g.n),
+                            wrap_cell(home_cell_i(hc, z), g.n));
+        flag = in_domain(g, sp, x, y, z) ? 0 : kSortFlagNoScatter;
+        slot = (int)(((unsigned)t * 2654435761u) >> 23) & (kSlots - 1);
+        for (;;) {
+          const int old = atomicCAS(&hkey[slot], 0, t + 1);
+          if (old == 0 || old == t + 1) break;
+          slot = (slot + 1) & (kSlots - 1);
+        }
+        local = atomicAdd(&hcnt[slot], 1);
+      } else {
+        V[p] = T(0);
+        V[p + g.N] = T(0);
+        V[p + 2 * g.N] = T(0);
+      }
+    }
+    __syncthreads();
+    for (int s = threadIdx.x; s < kSlots; s += blockDim.x)
+      if (hkey[s]) hbase[s] = atomicAdd(&cnt[hkey[s] - 1], hcnt[s]);
+    __syncthreads();
+    if (live && DIRECT) {
+      if (t >= 0) {
+        const int rank = hbase[slot] + local;
+        if (rank >= tp.cap) {
+          ovf[0] = 1;  // benign race: every writer stores 1
+          ovf[1] = 1;  // sticky copy: the host enlarges the slots before the next trajectory
+        } else {
+          const long long dst = (long long)t * tp.cap + rank;
+          sx[dst] = x;
+          sy[dst] = y;
+          sz[dst] = z;
+          sidx[dst] = (int)p | flag;
+        }
+      }
+    } else if (live) {
+      tile_rank[p] = (t < 0) ? make_int2(-1, 0) : make_int2(t, (hbase[slot] + local) | flag);
+    }
+    __syncthreads();  // the hash table is reused by the next brick
   }
-  __syncthreads();
-  for (int s = threadIdx.x; s < kSlots; s += blockDim.x)
-    if (hkey[s]) hbase[s] = atomicAdd(&cnt[hkey[s] - 1], hcnt[s]);
-  __syncthreads();
-  if (live) tile_rank[p] = (t < 0) ? make_int2(-1, 0) : make_int2(t, (hbase[slot] + local) | flag);
 }
 
-// Pass 2 (one workgroup): exclusive scans of the tile counts (-> record offsets) and of the per-tile chunk
-// counts (-> work-item offsets).  off and woff have ntiles + 1 entries.
+// One workgroup: record range [off, tend) of every tile -- fixed slots after a successful one-pass binning, an
+// exclusive scan of the fallback's counts otherwise -- and the exclusive scan of the per-tile chunk counts
+// (-> work-item offsets, ntiles + 1 entries).
 __device__ __forceinline__ int block_exclusive_scan_1024(int v, int *buf) {
   const int tid = threadIdx.x;
   buf[tid] = v;
@@ -1161,8 +1189,11 @@ __device__ __forceinline__ int block_exclusive_scan_1024(int v, int *buf) {
 }
 
 __global__ void __launch_bounds__(1024)
-k_scan_tiles(TilePar tp, const int *__restrict__ cnt, int *__restrict__ off, int *__restrict__ woff) {
+k_scan_tiles(TilePar tp, const int *__restrict__ cnt_direct, const int *__restrict__ cnt_fallback,
+             const int *__restrict__ ovf, int *__restrict__ off, int *__restrict__ tend, int *__restrict__ woff) {
   __shared__ int buf[1024];
+  const bool direct = !*ovf;
+  const int *cnt = direct ? cnt_direct : cnt_fallback;
   const int T = tp.ntiles, tid = threadIdx.x;
   const int per = (T + 1023) / 1024;
   const int lo = min(tid * per, T), hi = min(lo + per, T);
@@ -1174,40 +1205,42 @@ k_scan_tiles(TilePar tp, const int *__restrict__ cnt, int *__restrict__ off, int
   int ea = block_exclusive_scan_1024(a, buf);
   int eb = block_exclusive_scan_1024(b, buf);
   for (int t = lo; t < hi; t++) {
-    off[t] = ea;
+    const int o = direct ? t * tp.cap : ea;  // one-pass layout: fixed slots per tile; fallback: packed
+    off[t] = o;
+    tend[t] = o + cnt[t];
     woff[t] = eb;
     ea += cnt[t];
     eb += (cnt[t] + tp.chunk - 1) / tp.chunk;
   }
-  if (tid == 1023) {
-    off[T] = ea;
-    woff[T] = eb;
+  if (tid == 1023) woff[T] = eb;
+}
+
+// Fallback pass 3: write each particle's record (position, original index | flag) to its sorted slot.
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_reorder(Geo g, PosPar pp, int nbricks, const T *__restrict__ psi, const int2 *__restrict__ tile_rank,
+          const int *__restrict__ off, const int *__restrict__ ovf, T *__restrict__ sx, T *__restrict__ sy,
+          T *__restrict__ sz, int *__restrict__ sidx) {
+  if (!*ovf) return;  // the one-pass binning succeeded
+  for (int brick = blockIdx.x; brick < nbricks; brick += gridDim.x) {
+    int i, j, k;
+    const long long p = brick_particle(g, brick, i, j, k);
+    if (p >= g.N) continue;
+    const int2 tr = tile_rank[p];
+    if (tr.x < 0) continue;
+    T x, y, z;
+    particle_pos<T>(pp, i, j, k, psi[p], psi[p + g.N], psi[p + 2 * g.N], x, y, z);
+    const int slot = off[tr.x] + (tr.y & ~kSortFlagNoScatter);
+    sx[slot] = x;
+    sy[slot] = y;
+    sz[slot] = z;
+    sidx[slot] = (int)p | (tr.y & kSortFlagNoScatter);
   }
 }
 
-// Pass 3: write each particle's record (position, original index | flag) to its sorted slot.
-template <typename T>
-__global__ void __launch_bounds__(256)
-k_reorder(Geo g, PosPar pp, const T *__restrict__ psi, const int2 *__restrict__ tile_rank,
-          const int *__restrict__ off, T *__restrict__ sx, T *__restrict__ sy, T *__restrict__ sz,
-          int *__restrict__ sidx) {
-  int i, j, k;
-  const long long p = brick_particle(g, i, j, k);
-  if (p >= g.N) return;
-  const int2 tr = tile_rank[p];
-  if (tr.x < 0) return;
-  T x, y, z;
-  particle_pos<T>(pp, i, j, k, psi[p], psi[p + g.N], psi[p + 2 * g.N], x, y, z);
-  const int slot = off[tr.x] + (tr.y & ~kSortFlagNoScatter);
-  sx[slot] = x;
-  sy[slot] = y;
-  sz[slot] = z;
-  sidx[slot] = (int)p | (tr.y & kSortFlagNoScatter);
-}
-
 // Work item -> (tile, particle range).  Returns false when this workgroup has nothing to do.
-__device__ __forceinline__ bool tile_work(const TilePar &tp, const int *__restrict__ off, const int *__restrict__ woff,
-                                          int &tile, int &p_begin, int &p_end) {
+__device__ __forceinline__ bool tile_work(const TilePar &tp, const int *__restrict__ off, const int *__restrict__ tend,
+                                          const int *__restrict__ woff, int &tile, int &p_begin, int &p_end) {
   __shared__ int s_tile, s_b, s_e;
   if (threadIdx.x == 0) {
     const int w = blockIdx.x;
@@ -1220,7 +1253,7 @@ __device__ __forceinline__ bool tile_work(const TilePar &tp, const int *__restri
       }
       t = lo;
       b = off[t] + (w - woff[t]) * tp.chunk;
-      e = min(b + tp.chunk, off[t + 1]);
+      e = min(b + tp.chunk, tend[t]);
     }
     s_tile = t;
     s_b = b;
@@ -1293,11 +1326,12 @@ __device__ __forceinline__ void subsort_subcell(int bits, int pb, int pe, T inv_
 template <typename T>
 __global__ void __launch_bounds__(256)
 k_scatter_tile(Geo g, SphPar sp, TilePar tp, const int4 *__restrict__ cols, int ncol, int reorder, T *sx, T *sy, T *sz,
-               int *sidx, const int *__restrict__ off, const int *__restrict__ woff, T *__restrict__ rho) {
+               int *sidx, const int *__restrict__ off, const int *__restrict__ tend, const int *__restrict__ woff,
+               T *__restrict__ rho) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw_scatter[];
   double *s_tile_acc = reinterpret_cast<double *>(s_raw_scatter);  // accumulate in double also for float fields
   int tile, pb, pe;
-  if (!tile_work(tp, off, woff, tile, pb, pe)) return;
+  if (!tile_work(tp, off, tend, woff, tile, pb, pe)) return;
   const int ncell = tp.lx * tp.ly * tp.lz;
   int4 *s_cols = reinterpret_cast<int4 *>(s_raw_scatter + (((size_t)ncell * sizeof(double) + 15) & ~(size_t)15));
   for (int m = threadIdx.x; m < ncol; m += blockDim.x) s_cols[m] = cols[m];
@@ -1374,11 +1408,12 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 k_gather_tile(Geo g, HullPar hp, TilePar tp, int rsd, const T *__restrict__ sx, const T *__restrict__ sy,
               const T *__restrict__ sz, const int *__restrict__ sidx, const int *__restrict__ off,
-              const int *__restrict__ woff, const T *__restrict__ plike, T *__restrict__ V) {
+              const int *__restrict__ tend, const int *__restrict__ woff, const T *__restrict__ plike,
+              T *__restrict__ V) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw_gather[];
   T *s_tile_pl = reinterpret_cast<T *>(s_raw_gather);
   int tile, pb, pe;
-  if (!tile_work(tp, off, woff, tile, pb, pe)) return;
+  if (!tile_work(tp, off, tend, woff, tile, pb, pe)) return;
   const int ncell = tp.lx * tp.ly * tp.lz;
   int4 *s_cols = reinterpret_cast<int4 *>(s_raw_gather + (((size_t)ncell * sizeof(T) + 15) & ~(size_t)15));
   for (int m = threadIdx.x; m < hp.ncol; m += blockDim.x) s_cols[m] = hp.cols[m];
@@ -1451,11 +1486,12 @@ __host__ __device__ constexpr int hull81_zw(int a, int b) {
 template <typename T, int LY, int LZ>
 __global__ void __launch_bounds__(256)
 k_scatter_tile81(Geo g, SphPar sp, TilePar tp, int reorder, T *sx, T *sy, T *sz, int *sidx,
-                 const int *__restrict__ off, const int *__restrict__ woff, T *__restrict__ rho) {
+                 const int *__restrict__ off, const int *__restrict__ tend, const int *__restrict__ woff,
+                 T *__restrict__ rho) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw_scatter81[];
   double *s_tile_acc = reinterpret_cast<double *>(s_raw_scatter81);
   int tile, pb, pe;
-  if (!tile_work(tp, off, woff, tile, pb, pe)) return;
+  if (!tile_work(tp, off, tend, woff, tile, pb, pe)) return;
   const int ncell = tp.lx * LY * LZ;
   for (int c = threadIdx.x; c < ncell; c += blockDim.x) s_tile_acc[c] = 0.;
   const T d = (T)g.d;
@@ -1520,11 +1556,12 @@ template <typename T, int LY, int LZ>
 __global__ void __launch_bounds__(256)
 k_gather_tile81(Geo g, HullPar hp, TilePar tp, int rsd, const T *__restrict__ sx, const T *__restrict__ sy,
                 const T *__restrict__ sz, const int *__restrict__ sidx, const int *__restrict__ off,
-                const int *__restrict__ woff, const T *__restrict__ plike, T *__restrict__ V) {
+                const int *__restrict__ tend, const int *__restrict__ woff, const T *__restrict__ plike,
+                T *__restrict__ V) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw_gather81[];
   T *s_tile_pl = reinterpret_cast<T *>(s_raw_gather81);
   int tile, pb, pe;
-  if (!tile_work(tp, off, woff, tile, pb, pe)) return;
+  if (!tile_work(tp, off, tend, woff, tile, pb, pe)) return;
   const int ncell = tp.lx * LY * LZ;
   const int n = g.n;
   const int tzi = tile % tp.ntz, tyi = (tile / tp.ntz) % tp.nty, txi = tile / (tp.ntz * tp.nty);

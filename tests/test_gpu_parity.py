@@ -272,6 +272,23 @@ def test_other_tilings_and_kernel_sizes(nx, kw):
     e.close()
 
 
+@pytest.mark.parametrize("cap", ["0", "8", "1100"], ids=["two_pass_only", "overflow_fallback", "tight_cap"])
+def test_tile_sort_fallback_paths(monkeypatch, cap):
+    """The one-pass tile binning reserves BCHMC_SORT_CAP record slots per tile (default 4x the mean occupancy); when a
+    tile overflows, or with the one-pass path disabled (0), the two-pass counting sort produces the records."""
+    monkeypatch.setenv("BCHMC_SORT_CAP", cap)
+    c = Case(Nx=16, likelihood=1, rsd_model=1)
+    e = c.engine()
+    g, _, _ = c.oracle.gradient_psi(c.q0)
+    assert rel_l2(e.gradient(c.q0), g) < 10 * TOL_FIELD
+    assert rel_l2(e.fetch("rho"), c.oracle.getDensity(3, *[c.oracle.get(k) for k in ("posx", "posy", "posz")])) < TOL_FIELD
+    q1o, p1o, _ = c.oracle.Hamiltonian_EoM(c.q0, c.p0, c.eps, 5)
+    for _ in range(9):  # after an overflow the slots double before the next trajectory: 8 -> ... -> 2048 >= occupancy
+        q1, p1, _ = e.leapfrog(c.q0, c.p0, c.eps, 5)
+        assert rel_l2(q1, q1o) < TOL_TRAJ_10 and rel_l2(p1, p1o) < TOL_TRAJ_10
+    e.close()
+
+
 def test_direct_kernels_when_tiling_is_disabled(monkeypatch):
     """BCHMC_NO_TILES=1 forces the unsorted scatter/gather kernels (IEEE sqrt/divide, global atomics)."""
     monkeypatch.setenv("BCHMC_NO_TILES", "1")
