@@ -321,7 +321,9 @@ int grow_sort_slots(bchmc_handle *h) {
   HIPCHK(hipMemsetAsync(sticky, 0, sizeof(int), h->stream));
   const long long cap = 2ll * h->tp.cap;
   h->sorted_valid = false;
-  if (cap * h->tp.ntiles >= (1ll << 31)) {
+  const long long mean_occ = (long long)h->tp.tx * h->tp.ty * h->tp.tz;
+  if (cap * h->tp.ntiles >= (1ll << 31) || cap > 32 * std::max<long long>(mean_occ, 64)) {
+    // a tile holding more than 32x the mean is a pathological field: keep the two-pass sort instead of more memory
     h->sort_direct = false;
     return BCHMC_OK;
   }
