@@ -1,0 +1,174 @@
+"""ctypes view of the compiled C++ host layer (``barcode_amd/shim/hmc_hip_shim.cc``, ``include/bchmc_shim.hpp``).
+
+The C++ layer is the product's host side in the reference's language: ``Hamiltonian_EoM``, ``delta_Hamiltonian``,
+``gradient_psi``, ``measure_spectrum`` on a view of ``HAMIL_DATA`` / ``HAMIL_NUMERICAL``, throwing
+``std::runtime_error`` like the reference.  This module only exists so that the test-suite can drive that compiled
+code (through its ``extern "C"`` hooks) with the same seeded cases it uses everywhere else.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import engine as _engine
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_lib = None
+
+SHIM_EXPORTS = ("bchmc_shim_Hamiltonian_EoM", "bchmc_shim_delta_Hamiltonian", "bchmc_shim_gradient_psi",
+                "bchmc_shim_measure_spectrum", "bchmc_shim_release", "bchmc_shim_sizeof_view",
+                "bchmc_shim_sizeof_numerical")
+
+_dp = C.POINTER(C.c_double)
+
+
+class HamilNumericalView(C.Structure):
+    """bchmc_shim::HamilNumericalView (members of HAMIL_NUMERICAL, struct_hamil.h:51-144)."""
+    _fields_ = [
+        ("N1", C.c_uint), ("N", C.c_ulong),
+        ("L1", C.c_double), ("min1", C.c_double), ("min2", C.c_double), ("min3", C.c_double),
+        ("xobs", C.c_double), ("yobs", C.c_double), ("zobs", C.c_double),
+        ("planepar", C.c_bool), ("periodic", C.c_bool),
+        ("mk", C.c_int), ("calc_h", C.c_int), ("mass_type", C.c_int),
+        ("correct_delta", C.c_bool), ("div_dH_by_N", C.c_bool),
+        ("particle_kernel_h", C.c_double), ("kth", C.c_double),
+        ("grad_psi_prior_factor", C.c_double), ("grad_psi_likeli_factor", C.c_double), ("deltaQ_factor", C.c_double),
+        ("N_eps_fac", C.c_double), ("eps_fac", C.c_double), ("epsilon", C.c_double), ("Neps", C.c_ulong),
+        ("dH", C.c_double), ("dK", C.c_double), ("dE", C.c_double), ("dprior", C.c_double), ("dlikeli", C.c_double),
+        ("psi_prior", C.c_double), ("psi_likeli", C.c_double),
+        ("psi_prior_i", C.c_double), ("psi_prior_f", C.c_double), ("psi_likeli_i", C.c_double),
+        ("psi_likeli_f", C.c_double), ("H_kin_i", C.c_double), ("H_kin_f", C.c_double),
+    ]
+
+
+class HamilView(C.Structure):
+    """bchmc_shim::HamilView (members of HAMIL_DATA, struct_hamil.h:146-222)."""
+    _fields_ = [
+        ("numerical", C.POINTER(HamilNumericalView)),
+        ("likelihood", C.c_int), ("sfmodel", C.c_int), ("rsd_model", C.c_bool),
+        ("rho_c", C.c_double), ("delta_min", C.c_double), ("biasP", C.c_double), ("biasE", C.c_double),
+        ("ascale", C.c_double), ("D1", C.c_double), ("D2", C.c_double), ("OM", C.c_double), ("OL", C.c_double),
+        ("signal_PS", _dp), ("mass_f", _dp), ("mass_r", _dp), ("nobs", _dp), ("noise", _dp), ("window", _dp),
+        ("gradpsi", _dp), ("deltaX", _dp), ("posx", _dp), ("posy", _dp), ("posz", _dp),
+        ("device", C.c_int), ("engine", C.c_void_p),
+    ]
+
+
+UNIFORM_FN = C.CFUNCTYPE(C.c_double, C.c_void_p)
+
+
+def load():
+    """Load libbarcode_shim.so (after libbarcode_hip.so, which it links).  Fails loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    _engine.load()
+    path = os.path.join(_HERE, "libbarcode_shim.so")
+    if not os.path.exists(path):
+        raise ImportError("%s is missing: run `make -C barcode_amd/shim` (after barcode_amd/csrc)" % path)
+    lib = C.CDLL(path)
+    for s in SHIM_EXPORTS:
+        getattr(lib, s)
+    hv, sz, ul = C.POINTER(HamilView), C.c_size_t, C.c_ulong
+    lib.bchmc_shim_sizeof_view.restype = sz
+    lib.bchmc_shim_sizeof_numerical.restype = sz
+    lib.bchmc_shim_Hamiltonian_EoM.argtypes = [hv, _dp, _dp, _dp, _dp, UNIFORM_FN, C.c_void_p, C.POINTER(ul),
+                                               C.POINTER(ul), C.c_char_p, sz]
+    lib.bchmc_shim_delta_Hamiltonian.argtypes = [hv, _dp, _dp, _dp, _dp, _dp, C.c_char_p, sz]
+    lib.bchmc_shim_gradient_psi.argtypes = [hv, _dp, C.c_char_p, sz]
+    lib.bchmc_shim_measure_spectrum.argtypes = [hv, _dp, _dp, _dp, ul, C.c_char_p, sz]
+    lib.bchmc_shim_release.argtypes = [hv]
+    lib.bchmc_shim_release.restype = None
+    if lib.bchmc_shim_sizeof_view() != C.sizeof(HamilView) or \
+            lib.bchmc_shim_sizeof_numerical() != C.sizeof(HamilNumericalView):
+        raise ImportError("bchmc_shim.hpp and barcode_amd/shim.py disagree on the struct layouts")
+    _lib = lib
+    return lib
+
+
+class ShimError(RuntimeError):
+    """The C++ layer threw std::runtime_error."""
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp)
+
+
+class ShimHamil:
+    """A HAMIL_DATA view filled from HamilParams + arrays, driving the compiled C++ functions."""
+
+    def __init__(self, params, N_eps_fac=8.0, eps_fac=None, device=0, **arrays):
+        self.lib = load()
+        p = params
+        self.N = p.N
+        n = HamilNumericalView()
+        n.N1, n.N, n.L1 = p.Nx, p.N, p.L
+        for k in ("min1", "min2", "min3", "xobs", "yobs", "zobs", "mk", "calc_h", "mass_type", "particle_kernel_h",
+                  "kth", "grad_psi_prior_factor", "grad_psi_likeli_factor", "deltaQ_factor"):
+            setattr(n, k, getattr(p, k))
+        n.planepar, n.periodic = bool(p.planepar), bool(p.periodic)
+        n.correct_delta, n.div_dH_by_N = bool(p.correct_delta), bool(p.div_dH_by_N)
+        n.N_eps_fac = N_eps_fac
+        n.eps_fac = p.eps_heuristic() if eps_fac is None else eps_fac
+        self.numerical = n
+        hd = HamilView()
+        hd.numerical = C.pointer(n)
+        hd.likelihood, hd.sfmodel, hd.rsd_model = p.likelihood, p.sfmodel, bool(p.rsd_model)
+        for k in ("rho_c", "delta_min", "biasP", "biasE", "ascale", "D1", "D2", "OM", "OL"):
+            setattr(hd, k, getattr(p, k))
+        self._keep = {}
+        for k in ("signal_PS", "mass_f", "mass_r", "nobs", "noise", "window"):
+            if arrays.get(k) is not None:
+                a = np.ascontiguousarray(arrays[k], dtype=np.float64).reshape(-1)
+                self._keep[k] = a
+                setattr(hd, k, _p(a))
+        for k in ("gradpsi", "deltaX", "posx", "posy", "posz"):
+            a = np.zeros(p.N)
+            self._keep[k] = a
+            setattr(hd, k, _p(a))
+        hd.device = device
+        self.hd = hd
+        self.count_attempts = C.c_ulong(0)
+        self._err = C.create_string_buffer(512)
+
+    def _chk(self, rc):
+        if rc:
+            raise ShimError(self._err.value.decode())
+
+    def _in(self, a):
+        a = np.ascontiguousarray(a, dtype=np.float64).reshape(-1)
+        assert a.size == self.N
+        return a
+
+    def Hamiltonian_EoM(self, signali, momentai, uniform):
+        qf, pf = np.empty(self.N), np.empty(self.N)
+        done = C.c_ulong(0)
+        cb = UNIFORM_FN(lambda _state: float(uniform()))
+        self._chk(self.lib.bchmc_shim_Hamiltonian_EoM(C.byref(self.hd), _p(self._in(signali)), _p(self._in(momentai)),
+                                                      _p(qf), _p(pf), cb, None, C.byref(self.count_attempts),
+                                                      C.byref(done), self._err, len(self._err)))
+        return qf, pf, int(done.value)
+
+    def delta_Hamiltonian(self, signali, momentai, signalf, momentaf):
+        dH = C.c_double(0)
+        self._chk(self.lib.bchmc_shim_delta_Hamiltonian(C.byref(self.hd), _p(self._in(signali)), _p(self._in(momentai)),
+                                                        _p(self._in(signalf)), _p(self._in(momentaf)), C.byref(dH),
+                                                        self._err, len(self._err)))
+        return dH.value
+
+    def gradient_psi(self, signal):
+        self._chk(self.lib.bchmc_shim_gradient_psi(C.byref(self.hd), _p(self._in(signal)), self._err, len(self._err)))
+        return self._keep["gradpsi"]
+
+    def measure_spectrum(self, signal, N_bin=200):
+        km, pw = np.empty(N_bin), np.empty(N_bin)
+        self._chk(self.lib.bchmc_shim_measure_spectrum(C.byref(self.hd), _p(self._in(signal)), _p(km), _p(pw), N_bin,
+                                                       self._err, len(self._err)))
+        return km, pw
+
+    def out(self, name):
+        """hd->gradpsi / deltaX / posx / posy / posz as the C++ layer left them."""
+        return self._keep[name]
+
+    def close(self):
+        self.lib.bchmc_shim_release(C.byref(self.hd))

@@ -176,3 +176,15 @@ def test_eps_stats_exchange_world_size_2_gloo(tmp_path):
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
         assert "ok" in o
+
+
+def test_cpp_host_layer_is_built_and_exports_its_hooks():
+    """libbarcode_shim.so (g++, include/bchmc_shim.hpp) loads, exports every extern "C" hook and agrees with the
+    ctypes mirrors on the struct layouts (no compute: no GPU needed)."""
+    import ctypes as C
+    from barcode_amd import shim
+    lib = shim.load()
+    for s in shim.SHIM_EXPORTS:
+        assert hasattr(lib, s)
+    assert lib.bchmc_shim_sizeof_view() == C.sizeof(shim.HamilView)
+    assert lib.bchmc_shim_sizeof_numerical() == C.sizeof(shim.HamilNumericalView)
