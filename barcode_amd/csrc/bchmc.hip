@@ -87,6 +87,12 @@ struct bchmc_handle {
   bool hull_exact = false;  // no cell of the (2 reach + 1)^3 cube outside the hull can pass r/h <= 2
   // tile-sorted particle-mesh path
   bool tiled = false;
+  // "planes" mode of the interior step boundary: 2-D (y, z) transforms by rocFFT, x passes inside k_step_boundary_x
+  rocfft_plan r2c2d = nullptr, c2r2d = nullptr;  // batch 3 n planes
+  void *xtw = nullptr;                           // n / 2 twiddles exp(-2 pi i r / n), C2<T>
+  int log2n = 0;
+  bool planes_ok = false;                        // plans + kernel available for this grid
+  bool planes_c2r = false, planes_r2c = false;   // per force evaluation: which transform the next FFT call uses
   bool sort_direct = false;  // one-pass tile binning into fixed slots (two-pass sort as overflow fallback)
   bool disp_alpt = false;    // Ck holds an ALPT displacement: forward_rest applies cellboundcomp after the C2R
   double alpt_wtot = 0.;     // kernelcomp's normalisation (sum of the real-space kernel), computed on first use
@@ -494,7 +500,7 @@ struct Pipe {
   // C2R of the three displacement components, mass assignment, sum of rho.  Lag2Eul.cc:90-131 / 363-423.
   static int forward_rest(bchmc_handle *h, int rsd) {
     if (rsd && !h->c.planepar) return h->fail(BCHMC_ERR_RSD_NOT_PLANEPAR, "non-plane-parallel RSD is not implemented");
-    CHK(fft_exec(h, h->c2r3, h->Ck, h->psi, BCHMC_K_FFT_C2R));
+    CHK(fft_exec(h, h->planes_c2r ? h->c2r2d : h->c2r3, h->Ck, h->psi, BCHMC_K_FFT_C2R));
     if (h->disp_alpt) {
       if (rsd) return h->fail(BCHMC_ERR_STATE, "ALPT displacement with the RSD routine");
       ProfScope ps(h, BCHMC_K_OTHER);
@@ -657,7 +663,7 @@ struct Pipe {
       }
       HIPCHK(hipGetLastError());
     }
-    CHK(fft_exec(h, h->r2c3, h->V, h->Ck, BCHMC_K_FFT_R2C));
+    CHK(fft_exec(h, h->planes_r2c ? h->r2c2d : h->r2c3, h->V, h->Ck, BCHMC_K_FFT_R2C));
     *like_mode = 0;
     return BCHMC_OK;
   }
@@ -817,6 +823,36 @@ struct Pipe {
     return BCHMC_OK;
   }
 
+  // k_step_boundary_x for this grid: n == PER * NT / KB with KB = 8 (fp64, NT = 256) or 16 (fp32, NT = 512)
+  static int launch_boundary_x(bchmc_handle *h, const CT *qi, const CT *pi, CT *qo, CT *po, const double *wM, double a,
+                               double b, double half_eps, double eps, double c_za, double *guard_slot, StepCtl ctl) {
+    constexpr int KB = 128 / (int)sizeof(CT);
+    constexpr int NT_BIG = sizeof(T) == 8 ? 256 : 512, NT_SMALL = NT_BIG / 4;  // small: n = 32, 64 (tests)
+    const int n = h->g.n, grid = n * (h->g.nhp / KB);
+    const size_t lds = ((size_t)n * KB + n / 2) * sizeof(CT);
+    const CT *tw = reinterpret_cast<const CT *>(h->xtw);
+#define BCHMC_LAUNCH_X(NT, PER)                                                                                    \
+  do {                                                                                                             \
+    auto kern = k_step_boundary_x<T, NT, PER>;                                                                     \
+    if (lds > 48 * 1024)                                                                                           \
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                 (int)lds));                                                                       \
+    kern<<<grid, NT, lds, h->stream>>>(h->g, h->log2n, tw, C(h->Ck), qi, pi, qo, po, h->wS, wM, a, b, half_eps,  \
+                                       eps, c_za, guard_slot, ctl);                                                \
+  } while (0)
+    switch (n) {
+      case 32: BCHMC_LAUNCH_X(NT_SMALL, 4); break;
+      case 64: BCHMC_LAUNCH_X(NT_SMALL, 8); break;
+      case 128: BCHMC_LAUNCH_X(NT_BIG, 4); break;
+      case 256: BCHMC_LAUNCH_X(NT_BIG, 8); break;
+      case 512: BCHMC_LAUNCH_X(NT_BIG, 16); break;
+      default: return h->fail(BCHMC_ERR_STATE, "planes mode is not available for n = %d", n);
+    }
+#undef BCHMC_LAUNCH_X
+    HIPCHK(hipGetLastError());
+    return BCHMC_OK;
+  }
+
   // The same trajectory with every interior "second half kick | first half kick + drift + Zel'dovich" pair done by
   // one kernel (k_step_boundary) on ping-pong state buffers.  Used for k-space masses and forward-model likelihoods.
   static int trajectory_fused(bchmc_handle *h, double eps, uint64_t neps, const Tap *tap, double a, const double *wM,
@@ -837,9 +873,16 @@ struct Pipe {
                                                                            C(h->Ck), 0.5 * eps, eps, c_za, ctl);
       HIPCHK(hipGetLastError());
     }
+    // planes mode: the SPH-adjoint path (three V components) with a supported grid
+    const bool planes = h->planes_ok && h->c.calc_h == 2 && h->c.mk == 3 && !env_on("BCHMC_NO_PLANES");
     for (uint64_t s = 0; s < neps; s++) {
-      CHK(force_sources(h, true, &like_mode, &b));
       const bool last = (s + 1 == neps);
+      h->planes_c2r = planes && s > 0;   // Psi^ left by k_step_boundary_x still needs only the (y, z) passes
+      h->planes_r2c = planes && !last;   // ... and V^ for it gets only those
+      const int rc = force_sources(h, true, &like_mode, &b);
+      const bool xmode = h->planes_r2c && like_mode == 0;
+      h->planes_c2r = h->planes_r2c = false;
+      CHK(rc);
       if (tap && tap->like_f && last) CHK(tap_loglike(h, tap->like_f));
       StepCtl ctl{h->stop, h->steps_done, s > 0 ? h->guard + (s - 1) : nullptr, guard_limit, s};
       void *qi = cur ? q1 : q0, *pi = cur ? p1 : p0, *qo = cur ? q0 : q1, *po = cur ? p0 : p1;
@@ -848,6 +891,9 @@ struct Pipe {
         k_step_boundary<T, true><<<nblk_stride(h->g.Nhp), 256, 0, h->stream>>>(
             h->g, C(h->Ck), C(qi), C(pi), C(qi), C(pi), C(h->gk), h->wS, wM, a, b, like_mode, 0.5 * eps, eps, c_za,
             h->guard + s, ctl);
+      } else if (xmode) {
+        CHK(launch_boundary_x(h, C(qi), C(pi), C(qo), C(po), wM, a, b, 0.5 * eps, eps, c_za, h->guard + s, ctl));
+        cur ^= 1;
       } else {
         k_step_boundary<T, false><<<nblk_stride(h->g.Nhp), 256, 0, h->stream>>>(
             h->g, C(h->Ck), C(qi), C(pi), C(qo), C(po), C(h->gk), h->wS, wM, a, b, like_mode, 0.5 * eps, eps, c_za,
@@ -1244,7 +1290,49 @@ int bchmc_create(const bchmc_config *cfg, bchmc_handle **out) {
                               inv));
     rocfft_plan_description_destroy(fwd);
     rocfft_plan_description_destroy(inv);
-    for (rocfft_plan p : {h->r2c1, h->c2r1, h->r2c3, h->c2r3}) {
+    {
+      // planes mode (k_step_boundary_x): n a power of two, whole 128-byte k-groups per row, a supported per-thread count
+      const int KB = 128 / (int)(2 * h->esz);
+      int l2 = 0;
+      while ((1 << l2) < g.n) l2++;
+      if ((1 << l2) == g.n && g.n >= 32 && g.n <= 512 && g.nhp % KB == 0) {
+        h->log2n = l2;
+        const size_t len2[2] = {(size_t)g.n, (size_t)g.n};
+        const size_t rs2[2] = {1, (size_t)g.n}, cs2[2] = {1, (size_t)g.nhp};
+        rocfft_plan_description f2 = nullptr, i2 = nullptr;
+        FFTCHK(rocfft_plan_description_create(&f2));
+        FFTCHK(rocfft_plan_description_create(&i2));
+        FFTCHK(rocfft_plan_description_set_data_layout(f2, rocfft_array_type_real, rocfft_array_type_hermitian_interleaved,
+                                                       nullptr, nullptr, 2, rs2, (size_t)g.n * g.n, 2, cs2,
+                                                       (size_t)g.n * g.nhp));
+        FFTCHK(rocfft_plan_description_set_data_layout(i2, rocfft_array_type_hermitian_interleaved, rocfft_array_type_real,
+                                                       nullptr, nullptr, 2, cs2, (size_t)g.n * g.nhp, 2, rs2,
+                                                       (size_t)g.n * g.n));
+        FFTCHK(rocfft_plan_create(&h->r2c2d, rocfft_placement_notinplace, rocfft_transform_type_real_forward, prec, 2, len2,
+                                  3 * (size_t)g.n, f2));
+        FFTCHK(rocfft_plan_create(&h->c2r2d, rocfft_placement_notinplace, rocfft_transform_type_real_inverse, prec, 2, len2,
+                                  3 * (size_t)g.n, i2));
+        rocfft_plan_description_destroy(f2);
+        rocfft_plan_description_destroy(i2);
+        // twiddles exp(-2 pi i r / n), r < n / 2, from the host's libm
+        std::vector<double> tw(g.n);
+        for (int r = 0; r < g.n / 2; r++) {
+          const double ang = -2. * M_PI * (double)r / (double)g.n;
+          tw[2 * r] = std::cos(ang);
+          tw[2 * r + 1] = std::sin(ang);
+        }
+        CHK(dev_alloc_bytes(h, &h->xtw, (size_t)g.n * h->esz));
+        if (h->f32) {
+          std::vector<float> twf(tw.begin(), tw.end());
+          HIPCHK(hipMemcpy(h->xtw, twf.data(), twf.size() * sizeof(float), hipMemcpyHostToDevice));
+        } else {
+          HIPCHK(hipMemcpy(h->xtw, tw.data(), tw.size() * sizeof(double), hipMemcpyHostToDevice));
+        }
+        h->planes_ok = true;
+      }
+    }
+    for (rocfft_plan p : {h->r2c1, h->c2r1, h->r2c3, h->c2r3, h->r2c2d, h->c2r2d}) {
+      if (!p) continue;
       size_t wb = 0;
       FFTCHK(rocfft_plan_get_work_buffer_size(p, &wb));
       h->work_bytes = std::max(h->work_bytes, wb);
@@ -1370,12 +1458,12 @@ void bchmc_destroy(bchmc_handle *h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   prof_collect(h);
   for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
-  for (rocfft_plan p : {h->r2c1, h->c2r1, h->r2c3, h->c2r3})
+  for (rocfft_plan p : {h->r2c1, h->c2r1, h->r2c3, h->c2r3, h->r2c2d, h->c2r2d})
     if (p) rocfft_plan_destroy(p);
   if (h->info) rocfft_execution_info_destroy(h->info);
   void *ptrs[] = {h->work,  h->wS,       h->wM,    h->qk,    h->pk,   h->gk,     h->Ck,         h->tC,   h->psi,
                   h->V,     h->rho,      h->plike, h->ioq,   h->iop,  h->gprior, h->glike,      h->conv, h->convF,
-                  h->dstage, h->cq, h->cp, h->qk2, h->pk2, h->part6, h->rho_part, h->partA, h->guard, h->stop, h->steps_done, h->hull,  h->t_cnt, h->t_off,
+                  h->dstage, h->cq, h->cp, h->qk2, h->pk2, h->xtw, h->part6, h->rho_part, h->partA, h->guard, h->stop, h->steps_done, h->hull,  h->t_cnt, h->t_off,
                   h->t_woff, h->t_end, h->t_rank,  h->sx,    h->sy,    h->sz,   h->sidx};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);

@@ -337,6 +337,37 @@ def test_padded_half_complex_rows(monkeypatch, kw):
     e.close()
 
 
+@pytest.mark.parametrize("nx,precision", [(32, 0), (32, 1), (64, 0)], ids=["n32_fp64", "n32_fp32", "n64_fp64"])
+def test_planes_mode_step_boundary(monkeypatch, nx, precision):
+    """Interior step boundaries in "planes" mode (2-D rocFFT transforms of the (y, z) planes, the x passes fused into
+    k_step_boundary_x) against the oracle and against the 3-D-transform path (BCHMC_NO_PLANES=1)."""
+    monkeypatch.setenv("BCHMC_FFT_PAD", "1")  # whole 128-byte k-groups per row (default only for n >= 128)
+    c = Case(Nx=nx, likelihood=1, rsd_model=1)
+    neps = 4
+    q1o, p1o, _ = c.oracle.Hamiltonian_EoM(c.q0, c.p0, c.eps, neps)
+    out = []
+    for no_planes in ("0", "1"):
+        monkeypatch.setenv("BCHMC_NO_PLANES", no_planes)
+        e = c.engine(precision=precision)
+        q1, p1, done = e.leapfrog(c.q0, c.p0, c.eps, neps)
+        assert done == neps
+        qb = pb = np.zeros(1)
+        if precision == 0:  # 1e50 is not representable in fp32 storage: the guard is an fp64 feature
+            p_bad = c.p0.copy().ravel()
+            p_bad[0] = 1e60
+            qb, pb, doneb = e.leapfrog(c.q0, p_bad, 1e-6, neps + 2)  # guard trips inside a planes-mode boundary
+            assert doneb == 1
+        out.append((q1, p1, qb, pb))
+        e.close()
+    tol = TOL_TRAJ_10 if precision == 0 else TOL_F32_TRAJ
+    for q1, p1, _, _ in out:
+        assert rel_l2(q1, q1o) < tol and rel_l2(p1, p1o) < tol
+    noise = 1e-13 if precision == 0 else 1e-5
+    assert rel_l2(out[0][0], out[1][0]) < noise and rel_l2(out[0][1], out[1][1]) < noise
+    if precision == 0:
+        assert rel_l2(out[0][2], out[1][2]) < noise and rel_l2(out[0][3], out[1][3]) < noise
+
+
 def test_device_resident_entry_points():
     """bchmc_leapfrog_device / bchmc_energies_device on torch tensors give the host-array results."""
     import torch
