@@ -1817,8 +1817,8 @@ k_spectrum(Geo g, const C2<T> *__restrict__ xk, int n_bin, double dk, double *__
 // which saves two of the six strided passes over the 3-component arrays (measured: 2-D batched transforms
 // 0.36 + 0.33 ms against 0.58 + 0.55 ms for the 3-D ones at 256^3 fp64, scripts/fft2d_bench.hip).
 //
-// One workgroup owns the x-columns of KB = 128 B / sizeof(complex) adjacent k at one j: n x KB elements per
-// component, staged in LDS; radix-4 decimation-in-time FFTs in place (bit-reversed fill, twiddles from a table).
+// One workgroup owns the x-columns of KB = 128 B / sizeof(complex) adjacent k at one j: n x KB elements,
+// staged in LDS, four transforms per workgroup (V_x and ky V_y + kz V_z forward; kx B and B inverse, see below); radix-4 decimation-in-time FFTs in place (bit-reversed fill, twiddles from a table).
 // FFT arithmetic in T (like rocFFT's plan precision), boundary arithmetic in double (like every k-space kernel).
 // Requires n a power of two with n == PER * NT / KB, and nhp a multiple of KB.
 // ======================================================================================================
@@ -1926,97 +1926,124 @@ k_step_boundary_x(Geo g, int log2n, const C2<T> *__restrict__ twiddle, C2<T> *Ck
   const double ky = kval(j, g.n, g.kfac), kz = kval(k, g.n, g.kfac);
   const int shift = 32 - log2n;
   double2 hk[kMaxPer];
-#pragma unroll
-  for (int m = 0; m < kMaxPer; m++) hk[m] = make_double2(0., 0.);
-  // ---- forward x pass of V^_x, V^_y, V^_z and h^ = sum_j (k_j / k^2)(Im V^_j, -Re V^_j) ----
-  for (int comp = 0; comp < 3; comp++) {
+  // ---- forward x passes.  ky and kz are constants of a column, so V^_y and V^_z go through ONE transform as
+  // ky V_y + kz V_z:  h^ = (1/k^2) [ kx (Im V^_x, -Re V^_x) + (Im W^, -Re W^) ],  W = ky V_y + kz V_z ----
+  for (int pass = 0; pass < 2; pass++) {
     __syncthreads();
     for (int m = 0; m < per; m++) {
       const int i = irow + rows * m;
-      s[(int)(__brev((unsigned)i) >> shift) * KB + c] = Ck[col + plane * i + comp * g.Nhp];
+      const long long e = col + plane * i;
+      C2<T> v;
+      if (pass == 0) {
+        v = Ck[e];
+      } else {
+        const C2<T> vy = Ck[e + g.Nhp], vz = Ck[e + 2 * g.Nhp];
+        v.x = (T)(ky * (double)vy.x + kz * (double)vz.x);
+        v.y = (T)(ky * (double)vy.y + kz * (double)vz.y);
+      }
+      s[(int)(__brev((unsigned)i) >> shift) * KB + c] = v;
     }
     __syncthreads();
     xfft_inplace<T>(s, tw, n, log2n, KB, false);
 #pragma unroll
     for (int m = 0; m < kMaxPer; m++) {
-      if (m < per) {
-        const int i = irow + rows * m;
+      const int i = irow + rows * m;
+      const C2<T> v = s[i * KB + c];
+      if (pass == 0) {
         const double kx = kval(i, g.n, g.kfac);
-        const double kmod = kx * kx + ky * ky + kz * kz;
-        const bool nyq = (i == g.n / 2) || (j == g.n / 2) || (k == g.n / 2);
-        if (kmod > 0 && !nyq) {
-          const double f = (comp == 0 ? kx : (comp == 1 ? ky : kz)) * (1 / kmod);  // as assemble_g
-          const C2<T> v = s[i * KB + c];
-          hk[m].x += f * (double)v.y;
-          hk[m].y -= f * (double)v.x;
-        }
+        hk[m] = make_double2(kx * (double)v.y, -(kx * (double)v.x));
+      } else {
+        hk[m].x += (double)v.y;
+        hk[m].y -= (double)v.x;
       }
     }
   }
-  // ---- boundary arithmetic (as k_step_boundary), Psi^ components kept for the inverse passes ----
+  // ---- boundary arithmetic (as k_step_boundary); the first inverse transform's input is filled on the way ----
+  // Psi^_j = k_j B with B = (1/k^2)(Im phi^, -Re phi^), phi^ = c_za q^': kx B is transformed on its own, B once for
+  // both the y and the z component (ky, kz are constants of the column again).
   double gsum = 0.;
+  __syncthreads();
 #pragma unroll
   for (int m = 0; m < kMaxPer; m++) {
-    if (m < per) {
-      const int i = irow + rows * m;
-      const long long idx = col + plane * i;
-      double2 q = ld2<T>(q_in, idx);
-      double2 gg = make_double2(b * hk[m].x, b * hk[m].y);
-      if (a != 0.) {
-        const double w = a * wS[idx];
-        gg.x += w * q.x;
-        gg.y += w * q.y;
-      }
-      double2 p = ld2<T>(p_in, idx);
-      C2<T> pe, gs;
-      pe.x = (T)(p.x - half_eps * gg.x);
-      pe.y = (T)(p.y - half_eps * gg.y);
-      gs.x = (T)gg.x;
-      gs.y = (T)gg.y;
-      const double hw = (k == 0 || ((g.n & 1) == 0 && k == g.n / 2)) ? 1. : 2.;
-      if (k < g.nh) gsum += hw * (double)pe.x;
-      p.x = (double)pe.x - half_eps * (double)gs.x;
-      p.y = (double)pe.y - half_eps * (double)gs.y;
-      st2<T>(p_out, idx, p.x, p.y);
-      if (wM) {
-        const double w = wM[idx];
-        q.x += eps * (w * p.x);
-        q.y += eps * (w * p.y);
-      }
-      st2<T>(q_out, idx, q.x, q.y);
+    const int i = irow + rows * m;
+    const long long idx = col + plane * i;
+    const double kx = kval(i, g.n, g.kfac);
+    const double ksq = kx * kx + ky * ky + kz * kz;
+    const bool nyq = (i == g.n / 2) || (j == g.n / 2) || (k == g.n / 2);
+    double2 q = ld2<T>(q_in, idx);
+    double2 gg = make_double2(0., 0.);
+    if (ksq > 0 && !nyq) {
+      const double f = b * (1 / ksq);
+      gg = make_double2(f * hk[m].x, f * hk[m].y);
     }
+    if (a != 0.) {
+      const double w = a * wS[idx];
+      gg.x += w * q.x;
+      gg.y += w * q.y;
+    }
+    double2 p = ld2<T>(p_in, idx);
+    C2<T> pe, gs;
+    pe.x = (T)(p.x - half_eps * gg.x);
+    pe.y = (T)(p.y - half_eps * gg.y);
+    gs.x = (T)gg.x;
+    gs.y = (T)gg.y;
+    const double hw = (k == 0 || ((g.n & 1) == 0 && k == g.n / 2)) ? 1. : 2.;
+    if (k < g.nh) gsum += hw * (double)pe.x;
+    p.x = (double)pe.x - half_eps * (double)gs.x;
+    p.y = (double)pe.y - half_eps * (double)gs.y;
+    st2<T>(p_out, idx, p.x, p.y);
+    if (wM) {
+      const double w = wM[idx];
+      q.x += eps * (w * p.x);
+      q.y += eps * (w * p.y);
+    }
+    st2<T>(q_out, idx, q.x, q.y);
+    C2<T> o;
+    o.x = T(0);
+    o.y = T(0);
+    if (ksq > 1.e-14 && !nyq) {
+      const double f = (1. / ksq) * kx;
+      o.x = (T)(f * (c_za * q.y));
+      o.y = (T)(f * -(c_za * q.x));
+    }
+    s[(int)(__brev((unsigned)i) >> shift) * KB + c] = o;
   }
-  // ---- Psi^_j = (k_j/k^2)(Im phi^, -Re phi^), phi^ = c_za q^, then the inverse x pass, per component ----
-  for (int comp = 0; comp < 3; comp++) {
-    __syncthreads();
-#pragma unroll
-    for (int m = 0; m < kMaxPer; m++) {
-      if (m < per) {
-        const int i = irow + rows * m;
-        const double kx = kval(i, g.n, g.kfac);
-        const double ksq = kx * kx + ky * ky + kz * kz;
-        const bool nyq = (i == g.n / 2) || (j == g.n / 2) || (k == g.n / 2);
-        C2<T> o;
-        o.x = T(0);
-        o.y = T(0);
-        if (ksq > 1.e-14 && !nyq) {
-          const double f = (1. / ksq) * (comp == 0 ? kx : (comp == 1 ? ky : kz));  // as k_kick_drift_za
-          // q' as stored (each thread re-reads its own stores: cheaper than 2 registers per element per thread;
-          // for T = float this is the rounded value, the separate kernels use the unrounded one)
-          const double2 qn = ld2<T>(q_out, col + plane * i);
-          const double pr = c_za * qn.x, pi = c_za * qn.y;
-          o.x = (T)(f * pi);
-          o.y = (T)(f * -pr);
-        }
-        s[(int)(__brev((unsigned)i) >> shift) * KB + c] = o;
-      }
+  __syncthreads();
+  xfft_inplace<T>(s, tw, n, log2n, KB, true);
+  for (int m = 0; m < per; m++) {
+    const int i = irow + rows * m;
+    Ck[col + plane * i] = s[i * KB + c];
+  }
+  __syncthreads();
+  for (int m = 0; m < per; m++) {
+    const int i = irow + rows * m;
+    const double kx = kval(i, g.n, g.kfac);
+    const double ksq = kx * kx + ky * ky + kz * kz;
+    const bool nyq = (i == g.n / 2) || (j == g.n / 2) || (k == g.n / 2);
+    C2<T> o;
+    o.x = T(0);
+    o.y = T(0);
+    if (ksq > 1.e-14 && !nyq) {
+      // q' as stored (each thread re-reads its own stores; for T = float this is the rounded value)
+      const double2 qn = ld2<T>(q_out, col + plane * i);
+      const double f = 1. / ksq;
+      o.x = (T)(f * (c_za * qn.y));
+      o.y = (T)(f * -(c_za * qn.x));
     }
-    __syncthreads();
-    xfft_inplace<T>(s, tw, n, log2n, KB, true);
-    for (int m = 0; m < per; m++) {
-      const int i = irow + rows * m;
-      Ck[col + plane * i + comp * g.Nhp] = s[i * KB + c];
-    }
+    s[(int)(__brev((unsigned)i) >> shift) * KB + c] = o;
+  }
+  __syncthreads();
+  xfft_inplace<T>(s, tw, n, log2n, KB, true);
+  for (int m = 0; m < per; m++) {
+    const int i = irow + rows * m;
+    const C2<T> v = s[i * KB + c];
+    C2<T> oy, oz;
+    oy.x = (T)(ky * (double)v.x);
+    oy.y = (T)(ky * (double)v.y);
+    oz.x = (T)(kz * (double)v.x);
+    oz.y = (T)(kz * (double)v.y);
+    Ck[col + plane * i + g.Nhp] = oy;
+    Ck[col + plane * i + 2 * g.Nhp] = oz;
   }
   gsum = block_sum(gsum, red);
   if (threadIdx.x == 0) atomic_add_r(guard_slot, gsum);
