@@ -146,7 +146,9 @@ namespace {
 int dev_alloc_bytes(bchmc_handle *h, void **p, size_t bytes) {
   hipError_t e = hipMalloc(p, bytes);
   if (e != hipSuccess) return h->fail(BCHMC_ERR_NOMEM, "hipMalloc(%zu bytes): %s", bytes, hipGetErrorString(e));
-  HIPCHK(hipMemset(*p, 0, bytes));  // row padding of the half-complex arrays must hold finite values
+  // zero-fill ON THE HANDLE'S STREAM (it is non-blocking: a null-stream memset could land after the first kernels
+  // that use the buffer); row padding of the half-complex arrays must hold finite values
+  HIPCHK(hipMemsetAsync(*p, 0, bytes, h->stream));
   return BCHMC_OK;
 }
 template <typename U>
@@ -391,7 +393,8 @@ int build_conv_table(bchmc_handle *h) {
     }
   }
   CHK(dev_alloc(h, &h->convF, (size_t)g.Nhp));
-  HIPCHK(hipMemcpy(h->convF, F.data(), F.size() * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpyAsync(h->convF, F.data(), F.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));  // F is a local vector
   return BCHMC_OK;
 }
 
@@ -1324,9 +1327,11 @@ int bchmc_create(const bchmc_config *cfg, bchmc_handle **out) {
         CHK(dev_alloc_bytes(h, &h->xtw, (size_t)g.n * h->esz));
         if (h->f32) {
           std::vector<float> twf(tw.begin(), tw.end());
-          HIPCHK(hipMemcpy(h->xtw, twf.data(), twf.size() * sizeof(float), hipMemcpyHostToDevice));
+          HIPCHK(hipMemcpyAsync(h->xtw, twf.data(), twf.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
+          HIPCHK(hipStreamSynchronize(h->stream));
         } else {
-          HIPCHK(hipMemcpy(h->xtw, tw.data(), tw.size() * sizeof(double), hipMemcpyHostToDevice));
+          HIPCHK(hipMemcpyAsync(h->xtw, tw.data(), tw.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+          HIPCHK(hipStreamSynchronize(h->stream));
         }
         h->planes_ok = true;
       }
@@ -1388,7 +1393,8 @@ int bchmc_create(const bchmc_config *cfg, bchmc_handle **out) {
       h->hull_exact = exact;
     }
     CHK(dev_alloc(h, &h->hull, cols.size()));
-    HIPCHK(hipMemcpy(h->hull, cols.data(), cols.size() * sizeof(int4), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpyAsync(h->hull, cols.data(), cols.size() * sizeof(int4), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
     // tile-sorted particle-mesh path: tiles of 8 x 8 x 16 cells (z fastest) when they divide the grid
     {
       TilePar &tp = h->tp;
