@@ -1,0 +1,250 @@
+// step_boundary_x.hpp -- Planes mode: step boundary with the x passes of both transforms fused in.
+// Part of the bchmc engine's kernel set; include through kernels.hpp (definition order matters).
+#pragma once
+#include "common.hpp"
+
+namespace bchmc {
+
+// ======================================================================================================
+// Step boundary with the x passes of both transforms fused in ("planes" mode).
+//
+// A 3-D real transform is the batched 2-D transform of the (y, z) planes followed by complex FFTs along x, and the
+// step boundary is element-wise in k-space.  So between the gather and the next scatter the pipeline can be
+//   rocFFT 2-D R2C over the 3 n planes of V  ->  THIS kernel: [x-FFT of the three V^ columns, the boundary
+//   arithmetic of k_step_boundary, inverse x-FFT of the three Psi^ columns]  ->  rocFFT 2-D C2R over the planes,
+// which saves two of the six strided passes over the 3-component arrays (measured: 2-D batched transforms
+// 0.36 + 0.33 ms against 0.58 + 0.55 ms for the 3-D ones at 256^3 fp64, scripts/fft2d_bench.hip).
+//
+// One workgroup owns the x-columns of KB = 128 B / sizeof(complex) adjacent k at one j: n x KB elements,
+// staged in LDS, four transforms per workgroup (V_x and ky V_y + kz V_z forward; kx B and B inverse, see below); radix-4 decimation-in-time FFTs in place (bit-reversed fill, twiddles from a table).
+// FFT arithmetic in T (like rocFFT's plan precision), boundary arithmetic in double (like every k-space kernel).
+// Requires n a power of two with n == PER * NT / KB, and nhp a multiple of KB.
+// ======================================================================================================
+template <typename T>
+__device__ __forceinline__ C2<T> cmul(const C2<T> a, const C2<T> b) {
+  C2<T> r;
+  r.x = a.x * b.x - a.y * b.y;
+  r.y = a.x * b.y + a.y * b.x;
+  return r;
+}
+
+// In-place decimation-in-time FFT of KB interleaved columns: s[i * KB + c], bit-reversed input order on entry,
+// natural order on exit.  Two radix-2 stages are fused into one radix-4 pass (4 LDS reads + 4 writes per 4 points
+// per two stages); an odd log2 n gets one plain radix-2 stage first.  tw[r] = exp(-2 pi i r / n), r < n / 2.
+template <typename T>
+__device__ __forceinline__ void xfft_inplace(C2<T> *__restrict__ s, const C2<T> *__restrict__ tw, int n, int log2n,
+                                             int KB, bool inverse) {
+  int st = 1;
+  if (log2n & 1) {  // stage 1: half = 1, twiddle 1
+    const int nb = (n >> 1) * KB;
+    for (int b = threadIdx.x; b < nb; b += blockDim.x) {
+      const int c = b % KB, i0 = (b / KB) << 1;
+      const C2<T> a = s[i0 * KB + c], x = s[(i0 + 1) * KB + c];
+      C2<T> o0, o1;
+      o0.x = a.x + x.x; o0.y = a.y + x.y;
+      o1.x = a.x - x.x; o1.y = a.y - x.y;
+      s[i0 * KB + c] = o0;
+      s[(i0 + 1) * KB + c] = o1;
+    }
+    __syncthreads();
+    st = 2;
+  }
+  const int nq = (n >> 2) * KB;
+  for (; st < log2n; st += 2) {  // stages st and st + 1
+    const int half = 1 << (st - 1);
+    const int t1 = n >> st, t2 = n >> (st + 1);  // twiddle strides of the two stages
+    for (int b = threadIdx.x; b < nq; b += blockDim.x) {
+      const int c = b % KB, bf = b / KB;
+      const int r = bf & (half - 1), grp = bf >> (st - 1);
+      const int j = (grp << (st + 1)) + r;
+      C2<T> w1 = tw[r * t1], w2 = tw[r * t2];
+      if (inverse) {
+        w1.y = -w1.y;
+        w2.y = -w2.y;
+      }
+      const C2<T> e0 = s[j * KB + c], e1 = s[(j + half) * KB + c], e2 = s[(j + 2 * half) * KB + c],
+                  e3 = s[(j + 3 * half) * KB + c];
+      const C2<T> m1 = cmul<T>(w1, e1), m3 = cmul<T>(w1, e3);
+      C2<T> a0, a1, a2, a3;
+      a0.x = e0.x + m1.x; a0.y = e0.y + m1.y;
+      a1.x = e0.x - m1.x; a1.y = e0.y - m1.y;
+      a2.x = e2.x + m3.x; a2.y = e2.y + m3.y;
+      a3.x = e2.x - m3.x; a3.y = e2.y - m3.y;
+      const C2<T> n2 = cmul<T>(w2, a2), n3 = cmul<T>(w2, a3);
+      // second-stage twiddle of the odd pair is w2 * exp(-+ i pi / 2): multiply by -i (forward) / +i (inverse)
+      C2<T> r3;
+      if (inverse) {
+        r3.x = -n3.y; r3.y = n3.x;
+      } else {
+        r3.x = n3.y; r3.y = -n3.x;
+      }
+      C2<T> o0, o1, o2, o3;
+      o0.x = a0.x + n2.x; o0.y = a0.y + n2.y;
+      o2.x = a0.x - n2.x; o2.y = a0.y - n2.y;
+      o1.x = a1.x + r3.x; o1.y = a1.y + r3.y;
+      o3.x = a1.x - r3.x; o3.y = a1.y - r3.y;
+      s[j * KB + c] = o0;
+      s[(j + half) * KB + c] = o1;
+      s[(j + 2 * half) * KB + c] = o2;
+      s[(j + 3 * half) * KB + c] = o3;
+    }
+    __syncthreads();
+  }
+}
+
+template <typename T, int NT, int PER>
+__global__ void __launch_bounds__(NT, 4)
+k_step_boundary_x(Geo g, int log2n, const C2<T> *__restrict__ twiddle, C2<T> *Ck, const C2<T> *q_in, const C2<T> *p_in,
+                  C2<T> *q_out, C2<T> *p_out, const double *__restrict__ wS, const double *__restrict__ wM, double a,
+                  double b, double half_eps, double eps, double c_za, double *guard_slot, StepCtl ctl) {
+  constexpr int KB = 128 / (int)sizeof(C2<T>);
+  constexpr int kMaxPer = PER;  // elements of one component per thread: n == PER * NT / KB (checked by the host)
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw_x[];
+  __shared__ double red[NT / 64];
+  if (*ctl.stop) return;
+  if (ctl.guard_prev && fabs(*ctl.guard_prev) > ctl.guard_limit) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      *ctl.steps_done = ctl.step_index;
+      __threadfence();
+      *ctl.stop = 1;
+    }
+    return;
+  }
+  const int n = g.n;
+  C2<T> *s = reinterpret_cast<C2<T> *>(s_raw_x);  // n * KB
+  C2<T> *tw = s + (size_t)n * KB;                 // n / 2
+  for (int t = threadIdx.x; t < n / 2; t += blockDim.x) tw[t] = twiddle[t];
+  const int ntk = g.nhp / KB;
+  const int j = blockIdx.x / ntk, k0 = (blockIdx.x % ntk) * KB;
+  const int c = threadIdx.x % KB, irow = threadIdx.x / KB;
+  constexpr int rows = NT / KB, per = PER;
+  const int k = k0 + c;
+  const long long plane = (long long)g.n * g.nhp;  // elements between consecutive i
+  const long long col = k + (long long)g.nhp * j;  // element (0, j, k)
+  const double ky = kval(j, g.n, g.kfac), kz = kval(k, g.n, g.kfac);
+  const int shift = 32 - log2n;
+  double2 hk[kMaxPer];
+  // ---- forward x passes.  ky and kz are constants of a column, so V^_y and V^_z go through ONE transform as
+  // ky V_y + kz V_z:  h^ = (1/k^2) [ kx (Im V^_x, -Re V^_x) + (Im W^, -Re W^) ],  W = ky V_y + kz V_z ----
+  for (int pass = 0; pass < 2; pass++) {
+    __syncthreads();
+    for (int m = 0; m < per; m++) {
+      const int i = irow + rows * m;
+      const long long e = col + plane * i;
+      C2<T> v;
+      if (pass == 0) {
+        v = Ck[e];
+      } else {
+        const C2<T> vy = Ck[e + g.Nhp], vz = Ck[e + 2 * g.Nhp];
+        v.x = (T)(ky * (double)vy.x + kz * (double)vz.x);
+        v.y = (T)(ky * (double)vy.y + kz * (double)vz.y);
+      }
+      s[(int)(__brev((unsigned)i) >> shift) * KB + c] = v;
+    }
+    __syncthreads();
+    xfft_inplace<T>(s, tw, n, log2n, KB, false);
+#pragma unroll
+    for (int m = 0; m < kMaxPer; m++) {
+      const int i = irow + rows * m;
+      const C2<T> v = s[i * KB + c];
+      if (pass == 0) {
+        const double kx = kval(i, g.n, g.kfac);
+        hk[m] = make_double2(kx * (double)v.y, -(kx * (double)v.x));
+      } else {
+        hk[m].x += (double)v.y;
+        hk[m].y -= (double)v.x;
+      }
+    }
+  }
+  // ---- boundary arithmetic (as k_step_boundary); the first inverse transform's input is filled on the way ----
+  // Psi^_j = k_j B with B = (1/k^2)(Im phi^, -Re phi^), phi^ = c_za q^': kx B is transformed on its own, B once for
+  // both the y and the z component (ky, kz are constants of the column again).
+  double gsum = 0.;
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < kMaxPer; m++) {
+    const int i = irow + rows * m;
+    const long long idx = col + plane * i;
+    const double kx = kval(i, g.n, g.kfac);
+    const double ksq = kx * kx + ky * ky + kz * kz;
+    const bool nyq = (i == g.n / 2) || (j == g.n / 2) || (k == g.n / 2);
+    double2 q = ld2<T>(q_in, idx);
+    double2 gg = make_double2(0., 0.);
+    if (ksq > 0 && !nyq) {
+      const double f = b * (1 / ksq);
+      gg = make_double2(f * hk[m].x, f * hk[m].y);
+    }
+    if (a != 0.) {
+      const double w = a * wS[idx];
+      gg.x += w * q.x;
+      gg.y += w * q.y;
+    }
+    double2 p = ld2<T>(p_in, idx);
+    C2<T> pe, gs;
+    pe.x = (T)(p.x - half_eps * gg.x);
+    pe.y = (T)(p.y - half_eps * gg.y);
+    gs.x = (T)gg.x;
+    gs.y = (T)gg.y;
+    const double hw = (k == 0 || ((g.n & 1) == 0 && k == g.n / 2)) ? 1. : 2.;
+    if (k < g.nh) gsum += hw * (double)pe.x;
+    p.x = (double)pe.x - half_eps * (double)gs.x;
+    p.y = (double)pe.y - half_eps * (double)gs.y;
+    st2<T>(p_out, idx, p.x, p.y);
+    if (wM) {
+      const double w = wM[idx];
+      q.x += eps * (w * p.x);
+      q.y += eps * (w * p.y);
+    }
+    st2<T>(q_out, idx, q.x, q.y);
+    C2<T> o;
+    o.x = T(0);
+    o.y = T(0);
+    if (ksq > 1.e-14 && !nyq) {
+      const double f = (1. / ksq) * kx;
+      o.x = (T)(f * (c_za * q.y));
+      o.y = (T)(f * -(c_za * q.x));
+    }
+    s[(int)(__brev((unsigned)i) >> shift) * KB + c] = o;
+  }
+  __syncthreads();
+  xfft_inplace<T>(s, tw, n, log2n, KB, true);
+  for (int m = 0; m < per; m++) {
+    const int i = irow + rows * m;
+    Ck[col + plane * i] = s[i * KB + c];
+  }
+  __syncthreads();
+  for (int m = 0; m < per; m++) {
+    const int i = irow + rows * m;
+    const double kx = kval(i, g.n, g.kfac);
+    const double ksq = kx * kx + ky * ky + kz * kz;
+    const bool nyq = (i == g.n / 2) || (j == g.n / 2) || (k == g.n / 2);
+    C2<T> o;
+    o.x = T(0);
+    o.y = T(0);
+    if (ksq > 1.e-14 && !nyq) {
+      // q' as stored (each thread re-reads its own stores; for T = float this is the rounded value)
+      const double2 qn = ld2<T>(q_out, col + plane * i);
+      const double f = 1. / ksq;
+      o.x = (T)(f * (c_za * qn.y));
+      o.y = (T)(f * -(c_za * qn.x));
+    }
+    s[(int)(__brev((unsigned)i) >> shift) * KB + c] = o;
+  }
+  __syncthreads();
+  xfft_inplace<T>(s, tw, n, log2n, KB, true);
+  for (int m = 0; m < per; m++) {
+    const int i = irow + rows * m;
+    const C2<T> v = s[i * KB + c];
+    C2<T> oy, oz;
+    oy.x = (T)(ky * (double)v.x);
+    oy.y = (T)(ky * (double)v.y);
+    oz.x = (T)(kz * (double)v.x);
+    oz.y = (T)(kz * (double)v.y);
+    Ck[col + plane * i + g.Nhp] = oy;
+    Ck[col + plane * i + 2 * g.Nhp] = oz;
+  }
+  gsum = block_sum(gsum, red);
+  if (threadIdx.x == 0) atomic_add_r(guard_slot, gsum);
+}
+
+}  // namespace bchmc

@@ -1,0 +1,629 @@
+// tiles.hpp -- Tile-sorted particle-mesh path: binning, scan, LDS scatter / gather kernels.
+// Part of the bchmc engine's kernel set; include through kernels.hpp (definition order matters).
+#pragma once
+#include "common.hpp"
+
+namespace bchmc {
+
+// ======================================================================================================
+// Tile-sorted particle-mesh path (the fast path for masskernel 3 when the tile shape divides the grid).
+//
+// Zel'dovich displacements at the BASELINE resolution are many cells long (rms 3-10 cells at 256^3 in a
+// 200 Mpc/h box), so a Lagrangian brick of particles does NOT stay inside an LDS-sized Eulerian tile.  We
+// therefore bin the particles by the Eulerian tile of their home cell every force evaluation (counting
+// sort: block-aggregated atomics, one scan, one reorder pass), and then
+//   * scatter: one workgroup per (tile, chunk of <= `chunk` particles) accumulates W into an LDS copy of the
+//     tile plus a halo of `R` cells with LDS float atomics and flushes its non-zero cells to HBM once
+//     (a few coalesced global atomics per cell instead of ~34 scattered ones per particle);
+//   * gather: the same work items stage part_like (tile + halo) in LDS and each particle reads its 81
+//     stencil cells from there.
+// The (particle, cell) pair set is identical to the direct kernels above, which stay as the fallback; the
+// spline evaluations use fast_rsqrt (<= 2 ulp) instead of IEEE sqrt + divide.
+// ======================================================================================================
+struct TilePar {
+  int tx, ty, tz;     // tile shape in cells (z fastest)
+  int ntx, nty, ntz;  // tiles per axis
+  int ntiles;
+  int R;              // halo = farthest stencil offset
+  int lx, ly, lz;     // LDS tile shape = t + 2R
+  int chunk;          // max particles per work item
+  int cap;            // record slots reserved per tile by the one-pass binning (k_bin<DIRECT>)
+};
+
+constexpr int kSortFlagNoScatter = 1 << 30;  // record flag: particle fails getDensity_SPH's domain test
+
+__device__ __forceinline__ int tile_of(const TilePar &tp, int n, long long ix, long long iy, long long iz) {
+  const int cx = (int)(ix % n), cy = (int)(iy % n), cz = (int)(iz % n);
+  return (cz / tp.tz) + tp.ntz * ((cy / tp.ty) + tp.nty * (cx / tp.tx));
+}
+
+// Home cell of a position: (ULONG)(xp/d1), massFunctions.cc:434-436.
+template <typename T>
+__device__ __forceinline__ long long home_cell(T x, T d) {
+  return (long long)(x / d);
+}
+
+// The same cell for the sorted path (positions there are in [0, L], so the result is in [0, n]) without the IEEE
+// divide: x * (1/d) is within a few ulp of x / d, so truncating it gives the reference's cell unless the quotient
+// is that close to an integer; only then is the division itself evaluated.  Deterministic in (x, d): the binning
+// pass and the scatter/gather passes always agree.
+template <typename T> struct HomeCell {
+  T d, inv_d, thr;
+  int n;
+};
+template <typename T>
+__device__ __forceinline__ HomeCell<T> make_home(const Geo &g) {
+  HomeCell<T> hc;
+  hc.d = (T)g.d;
+  hc.inv_d = T(1) / hc.d;
+  hc.thr = (T)g.n * (sizeof(T) == 8 ? T(1e-15) : T(5e-7));  // >= 4 ulp of the largest quotient
+  hc.n = g.n;
+  return hc;
+}
+template <typename T>
+__device__ __forceinline__ int home_cell_i(const HomeCell<T> &hc, T x) {
+  const T f = x * hc.inv_d;
+  if (__builtin_expect(fabs(f - rint(f)) < hc.thr, 0)) return (int)(x / hc.d);
+  return (int)f;
+}
+__device__ __forceinline__ int wrap_cell(int c, int n) { return c >= n ? c - n : c; }
+__device__ __forceinline__ int tile_of_wrapped(const TilePar &tp, int cx, int cy, int cz) {
+  return (cz / tp.tz) + tp.ntz * ((cy / tp.ty) + tp.nty * (cx / tp.tx));
+}
+
+// Workgroup -> particles.  When 16 divides n a workgroup takes a 4 x 4 x 16 brick of the Lagrangian lattice
+// (neighbours in space: few distinct tiles per workgroup, 128-byte rows of psi); otherwise 256 consecutive ones.
+__device__ __forceinline__ long long brick_particle(const Geo &g, int b, int &i, int &j, int &k) {
+  const int n = g.n, tid = threadIdx.x;
+  if ((n & 15) == 0) {
+    const int nbz = n >> 4, nby = n >> 2;
+    const int bk = b % nbz, bj = (b / nbz) % nby, bi = b / (nbz * nby);
+    i = bi * 4 + (tid >> 6);
+    j = bj * 4 + ((tid >> 4) & 3);
+    k = bk * 16 + (tid & 15);
+    return k + (long long)n * (j + (long long)n * i);
+  }
+  const long long p = b * (long long)blockDim.x + tid;
+  k = (int)(p % n);
+  const long long ij = p / n;
+  j = (int)(ij % n);
+  i = (int)(ij / n);
+  return p;
+}
+
+// Binning.  The workgroup first counts its particles per tile in an LDS hash table, then reserves one contiguous
+// rank range per distinct tile with a single global atomic (a handful per workgroup instead of one returning
+// atomic per particle on ~n^3/2048 hot counters).  Particles with a non-finite position are left out; the gather
+// gives them V = 0.
+//   DIRECT = true  (one-pass sort): every tile owns `tp.cap` record slots, the particle's record (position, index |
+//                  flag) goes straight to slot tile * cap + rank.  A rank >= cap raises *ovf and the record is dropped:
+//                  the two-pass kernels below then redo the sort from scratch (they return at once otherwise).
+//   DIRECT = false (two-pass fallback, pass 1): tile id and arrival rank of every particle to tile_rank.
+template <typename T, bool DIRECT>
+__global__ void __launch_bounds__(256)
+k_bin(Geo g, PosPar pp, SphPar sp, TilePar tp, int nbricks, const T *__restrict__ psi, int *__restrict__ cnt,
+      int *__restrict__ ovf,
+      int2 *__restrict__ tile_rank, T *__restrict__ sx, T *__restrict__ sy, T *__restrict__ sz, int *__restrict__ sidx,
+      T *__restrict__ V) {
+  constexpr int kSlots = 512;
+  __shared__ int hkey[kSlots], hcnt[kSlots], hbase[kSlots];
+  if (!DIRECT && !*ovf) return;
+  // DIRECT: one brick per workgroup; fallback: a small grid strides over the bricks (it usually returns above)
+  for (int brick = blockIdx.x; brick < nbricks; brick += gridDim.x) {
+    for (int s = threadIdx.x; s < kSlots; s += blockDim.x) {
+      hkey[s] = 0;
+      hcnt[s] = 0;
+    }
+    __syncthreads();
+    int i, j, k;
+    const long long p = brick_particle(g, brick, i, j, k);
+    const bool live = p < g.N;
+    int t = -1, slot = 0, local = 0, flag = 0;
+    T x = T(0), y = T(0), z = T(0);
+    if (live) {
+      particle_pos<T>(pp, i, j, k, psi[p], psi[p + g.N], psi[p + 2 * g.N], x, y, z);
+      if (pos_ok(g, x, y, z)) {
+        const HomeCell<T> hc = make_home<T>(g);
+        t = tile_of_wrapped(tp, wrap_cell(home_cell_i(hc, x), g.n), wrap_cell(home_cell_i(hc, y), g.n),
+                            wrap_cell(home_cell_i(hc, z), g.n));
+        flag = in_domain(g, sp, x, y, z) ? 0 : kSortFlagNoScatter;
+        slot = (int)(((unsigned)t * 2654435761u) >> 23) & (kSlots - 1);
+        for (;;) {
+          const int old = atomicCAS(&hkey[slot], 0, t + 1);
+          if (old == 0 || old == t + 1) break;
+          slot = (slot + 1) & (kSlots - 1);
+        }
+        local = atomicAdd(&hcnt[slot], 1);
+      } else {
+        V[p] = T(0);
+        V[p + g.N] = T(0);
+        V[p + 2 * g.N] = T(0);
+      }
+    }
+    __syncthreads();
+    for (int s = threadIdx.x; s < kSlots; s += blockDim.x)
+      if (hkey[s]) hbase[s] = atomicAdd(&cnt[hkey[s] - 1], hcnt[s]);
+    __syncthreads();
+    if (live && DIRECT) {
+      if (t >= 0) {
+        const int rank = hbase[slot] + local;
+        if (rank >= tp.cap) {
+          ovf[0] = 1;  // benign race: every writer stores 1
+          ovf[1] = 1;  // sticky copy: the host enlarges the slots before the next trajectory
+        } else {
+          const long long dst = (long long)t * tp.cap + rank;
+          sx[dst] = x;
+          sy[dst] = y;
+          sz[dst] = z;
+          sidx[dst] = (int)p | flag;
+        }
+      }
+    } else if (live) {
+      tile_rank[p] = (t < 0) ? make_int2(-1, 0) : make_int2(t, (hbase[slot] + local) | flag);
+    }
+    __syncthreads();  // the hash table is reused by the next brick
+  }
+}
+
+// One workgroup: record range [off, tend) of every tile -- fixed slots after a successful one-pass binning, an
+// exclusive scan of the fallback's counts otherwise -- and the exclusive scan of the per-tile chunk counts
+// (-> work-item offsets, ntiles + 1 entries).
+__device__ __forceinline__ int block_exclusive_scan_1024(int v, int *buf) {
+  const int tid = threadIdx.x;
+  buf[tid] = v;
+  __syncthreads();
+  for (int s = 1; s < 1024; s <<= 1) {
+    const int u = tid >= s ? buf[tid - s] : 0;
+    __syncthreads();
+    buf[tid] += u;
+    __syncthreads();
+  }
+  const int incl = buf[tid];
+  __syncthreads();
+  return incl - v;
+}
+
+__global__ void __launch_bounds__(1024)
+k_scan_tiles(TilePar tp, const int *__restrict__ cnt_direct, const int *__restrict__ cnt_fallback,
+             const int *__restrict__ ovf, int *__restrict__ off, int *__restrict__ tend, int *__restrict__ woff) {
+  __shared__ int buf[1024];
+  const bool direct = !*ovf;
+  const int *cnt = direct ? cnt_direct : cnt_fallback;
+  const int T = tp.ntiles, tid = threadIdx.x;
+  const int per = (T + 1023) / 1024;
+  const int lo = min(tid * per, T), hi = min(lo + per, T);
+  int a = 0, b = 0;
+  for (int t = lo; t < hi; t++) {
+    a += cnt[t];
+    b += (cnt[t] + tp.chunk - 1) / tp.chunk;
+  }
+  int ea = block_exclusive_scan_1024(a, buf);
+  int eb = block_exclusive_scan_1024(b, buf);
+  for (int t = lo; t < hi; t++) {
+    const int o = direct ? t * tp.cap : ea;  // one-pass layout: fixed slots per tile; fallback: packed
+    off[t] = o;
+    tend[t] = o + cnt[t];
+    woff[t] = eb;
+    ea += cnt[t];
+    eb += (cnt[t] + tp.chunk - 1) / tp.chunk;
+  }
+  if (tid == 1023) woff[T] = eb;
+}
+
+// Fallback pass 3: write each particle's record (position, original index | flag) to its sorted slot.
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_reorder(Geo g, PosPar pp, int nbricks, const T *__restrict__ psi, const int2 *__restrict__ tile_rank,
+          const int *__restrict__ off, const int *__restrict__ ovf, T *__restrict__ sx, T *__restrict__ sy,
+          T *__restrict__ sz, int *__restrict__ sidx) {
+  if (!*ovf) return;  // the one-pass binning succeeded
+  for (int brick = blockIdx.x; brick < nbricks; brick += gridDim.x) {
+    int i, j, k;
+    const long long p = brick_particle(g, brick, i, j, k);
+    if (p >= g.N) continue;
+    const int2 tr = tile_rank[p];
+    if (tr.x < 0) continue;
+    T x, y, z;
+    particle_pos<T>(pp, i, j, k, psi[p], psi[p + g.N], psi[p + 2 * g.N], x, y, z);
+    const int slot = off[tr.x] + (tr.y & ~kSortFlagNoScatter);
+    sx[slot] = x;
+    sy[slot] = y;
+    sz[slot] = z;
+    sidx[slot] = (int)p | (tr.y & kSortFlagNoScatter);
+  }
+}
+
+// Work item -> (tile, particle range).  Returns false when this workgroup has nothing to do.
+__device__ __forceinline__ bool tile_work(const TilePar &tp, const int *__restrict__ off, const int *__restrict__ tend,
+                                          const int *__restrict__ woff, int &tile, int &p_begin, int &p_end) {
+  __shared__ int s_tile, s_b, s_e;
+  if (threadIdx.x == 0) {
+    const int w = blockIdx.x;
+    int t = -1, b = 0, e = 0;
+    if (w < woff[tp.ntiles]) {
+      int lo = 0, hi = tp.ntiles;  // last t with woff[t] <= w
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (woff[mid] <= w) lo = mid; else hi = mid;
+      }
+      t = lo;
+      b = off[t] + (w - woff[t]) * tp.chunk;
+      e = min(b + tp.chunk, tend[t]);
+    }
+    s_tile = t;
+    s_b = b;
+    s_e = e;
+  }
+  __syncthreads();
+  tile = s_tile;
+  p_begin = s_b;
+  p_end = s_e;
+  return tile >= 0;
+}
+
+// Order one work item's records by the sub-cell position of the particle (in place; the gather reads the same
+// order): `bits` binary digits of the fractional cell coordinate per axis, octant digits most significant.  The 64
+// lanes of a wave then share most of the stencil cells that can pass the `r/h <= 2` test, and a wave pays for
+// every candidate ANY of its lanes needs (81 unsorted, ~51 with octants, fewer with 4 x 4 x 4 bins).  Pure
+// reordering: results do not depend on it.  Requires chunk == 256 * 8 and blockDim.x == 256.
+template <typename T>
+__device__ __forceinline__ void subsort_subcell(int bits, int pb, int pe, T inv_d, T *sx, T *sy, T *sz, int *sidx) {
+  constexpr int kPer = 8;  // tp.chunk == 256 * kPer
+  __shared__ int hist[64], base[64];
+  const int nb = 1 << (3 * bits);
+  if (threadIdx.x < 64) hist[threadIdx.x] = 0;
+  __syncthreads();
+  T rx[kPer], ry[kPer], rz[kPer];
+  int id[kPer], key[kPer], rank[kPer];
+  const T scale = (T)(1 << bits);
+#pragma unroll
+  for (int m = 0; m < kPer; m++) {
+    const int s = pb + (int)threadIdx.x + 256 * m;
+    if (s < pe) {
+      rx[m] = sx[s];
+      ry[m] = sy[s];
+      rz[m] = sz[s];
+      id[m] = sidx[s];
+      const T fx = rx[m] * inv_d, fy = ry[m] * inv_d, fz = rz[m] * inv_d;  // ordering only
+      const int ux = min((int)((fx - r_floor(fx)) * scale), (1 << bits) - 1);
+      const int uy = min((int)((fy - r_floor(fy)) * scale), (1 << bits) - 1);
+      const int uz = min((int)((fz - r_floor(fz)) * scale), (1 << bits) - 1);
+      int kk = 0;
+      for (int b = bits - 1; b >= 0; b--) kk = (kk << 3) | (((ux >> b) & 1) << 2) | (((uy >> b) & 1) << 1) | ((uz >> b) & 1);
+      key[m] = kk;
+      rank[m] = atomicAdd(&hist[kk], 1);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int acc = 0;
+    for (int b = 0; b < nb; b++) {
+      base[b] = acc;
+      acc += hist[b];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < kPer; m++) {
+    const int s = pb + (int)threadIdx.x + 256 * m;
+    if (s < pe) {
+      const int dst = pb + base[key[m]] + rank[m];
+      sx[dst] = rx[m];
+      sy[dst] = ry[m];
+      sz[dst] = rz[m];
+      sidx[dst] = id[m];
+    }
+  }
+  __threadfence_block();
+}
+
+// getDensity_SPH on sorted particles: LDS accumulation per (tile, chunk), one flush.
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_scatter_tile(Geo g, SphPar sp, TilePar tp, const int4 *__restrict__ cols, int ncol, int reorder, T *sx, T *sy, T *sz,
+               int *sidx, const int *__restrict__ off, const int *__restrict__ tend, const int *__restrict__ woff,
+               T *__restrict__ rho) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw_scatter[];
+  double *s_tile_acc = reinterpret_cast<double *>(s_raw_scatter);  // accumulate in double also for float fields
+  int tile, pb, pe;
+  if (!tile_work(tp, off, tend, woff, tile, pb, pe)) return;
+  const int ncell = tp.lx * tp.ly * tp.lz;
+  int4 *s_cols = reinterpret_cast<int4 *>(s_raw_scatter + (((size_t)ncell * sizeof(double) + 15) & ~(size_t)15));
+  for (int m = threadIdx.x; m < ncol; m += blockDim.x) s_cols[m] = cols[m];
+  for (int c = threadIdx.x; c < ncell; c += blockDim.x) s_tile_acc[c] = 0.;
+  const T d = (T)g.d;
+  const HomeCell<T> hc = make_home<T>(g);
+  if (reorder) subsort_subcell<T>(reorder, pb, pe, hc.inv_d, sx, sy, sz, sidx);
+  __syncthreads();
+  const int tzi = tile % tp.ntz, tyi = (tile / tp.ntz) % tp.nty, txi = tile / (tp.ntz * tp.nty);
+  const int ox = txi * tp.tx - tp.R, oy = tyi * tp.ty - tp.R, oz = tzi * tp.tz - tp.R;  // global cell of LDS (0,0,0)
+  const int n = g.n, R = sp.reach;
+  const T r2_lim = (T)sp.r2_lim, h_inv = (T)sp.h_inv, w_norm = (T)sp.w_norm;
+  for (int s = pb + threadIdx.x; s < pe; s += blockDim.x) {
+    if (sidx[s] & kSortFlagNoScatter) continue;
+    const T x = sx[s], y = sy[s], z = sz[s];
+    const int ix = home_cell_i(hc, x), iy = home_cell_i(hc, y), iz = home_cell_i(hc, z);
+    const T ccx = ((T)ix + T(0.5)) * d, ccy = ((T)iy + T(0.5)) * d, ccz = ((T)iz + T(0.5)) * d;
+    const int hx = wrap_cell(ix, n) - ox, hy = wrap_cell(iy, n) - oy, hz = wrap_cell(iz, n) - oz;  // home cell in LDS coords
+    if ((unsigned)(hx - tp.R) >= (unsigned)tp.tx || (unsigned)(hy - tp.R) >= (unsigned)tp.ty ||
+        (unsigned)(hz - tp.R) >= (unsigned)tp.tz)
+      continue;  // cannot happen (binning and this kernel see the same stored position); keeps LDS indexing safe
+    if (ncol > 0) {
+      // Exact hull (host-verified: no cell outside it can satisfy r/h <= 2): 81 candidates instead of 343.
+      for (int m = 0; m < ncol; ++m) {
+        const int4 c = s_cols[m];
+        const T dx = x - (ccx + (T)c.x * d);
+        const T dy = y - (ccy + (T)c.y * d);
+        const T r2ab = dx * dx + dy * dy;
+        if (r2ab > r2_lim) continue;
+        double *row = s_tile_acc + tp.lz * ((hy + c.y) + tp.ly * (hx + c.x)) + hz;
+        for (int i3 = c.z; i3 <= c.w; ++i3) {
+          const T dz = z - (ccz + (T)i3 * d);
+          const T r2 = r2ab + dz * dz;
+          if (r2 <= r2_lim) {
+            const T q = (r2 * fast_rsqrt(r2 + tiny_pos<T>())) * h_inv;
+            if (q <= T(2)) atomic_add_r(row + i3, (double)sph_w_folded<T>(q, w_norm));
+          }
+        }
+      }
+    } else {
+      for (int i1 = -R; i1 <= R; ++i1) {
+        const T dx = x - (ccx + (T)i1 * d);
+        const T dx2 = dx * dx;
+        if (dx2 > r2_lim) continue;
+        for (int i2 = -R; i2 <= R; ++i2) {
+          const T dy = y - (ccy + (T)i2 * d);
+          const T r2ab = dx2 + dy * dy;
+          if (r2ab > r2_lim) continue;
+          double *row = s_tile_acc + tp.lz * ((hy + i2) + tp.ly * (hx + i1)) + hz;
+          for (int i3 = -R; i3 <= R; ++i3) {
+            const T dz = z - (ccz + (T)i3 * d);
+            const T r2 = r2ab + dz * dz;
+            if (r2 > r2_lim) continue;
+            const T q = (r2 * fast_rsqrt(r2 + tiny_pos<T>())) * h_inv;
+            if (q <= T(2)) atomic_add_r(row + i3, (double)sph_w_folded<T>(q, w_norm));
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < ncell; c += blockDim.x) {
+    const double v = s_tile_acc[c];
+    if (v != 0.) {
+      const int cz = c % tp.lz, cy = (c / tp.lz) % tp.ly, cx = c / (tp.lz * tp.ly);
+      const int gx = (ox + cx + n) % n, gy = (oy + cy + n) % n, gz = (oz + cz + n) % n;
+      atomic_add_r(rho + gz + (long long)n * (gy + (long long)n * gx), (T)v);
+    }
+  }
+}
+
+// likelihood_calc_V_SPH on sorted particles: part_like tile + halo staged in LDS.
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_gather_tile(Geo g, HullPar hp, TilePar tp, int rsd, const T *__restrict__ sx, const T *__restrict__ sy,
+              const T *__restrict__ sz, const int *__restrict__ sidx, const int *__restrict__ off,
+              const int *__restrict__ tend, const int *__restrict__ woff, const T *__restrict__ plike,
+              T *__restrict__ V) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw_gather[];
+  T *s_tile_pl = reinterpret_cast<T *>(s_raw_gather);
+  int tile, pb, pe;
+  if (!tile_work(tp, off, tend, woff, tile, pb, pe)) return;
+  const int ncell = tp.lx * tp.ly * tp.lz;
+  int4 *s_cols = reinterpret_cast<int4 *>(s_raw_gather + (((size_t)ncell * sizeof(T) + 15) & ~(size_t)15));
+  for (int m = threadIdx.x; m < hp.ncol; m += blockDim.x) s_cols[m] = hp.cols[m];
+  const int n = g.n;
+  const int tzi = tile % tp.ntz, tyi = (tile / tp.ntz) % tp.nty, txi = tile / (tp.ntz * tp.nty);
+  const int ox = txi * tp.tx - tp.R, oy = tyi * tp.ty - tp.R, oz = tzi * tp.tz - tp.R;
+  for (int c = threadIdx.x; c < ncell; c += blockDim.x) {
+    const int cz = c % tp.lz, cy = (c / tp.lz) % tp.ly, cx = c / (tp.lz * tp.ly);
+    const int gx = (ox + cx + n) % n, gy = (oy + cy + n) % n, gz = (oz + cz + n) % n;
+    s_tile_pl[c] = plike[gz + (long long)n * (gy + (long long)n * gx)];
+  }
+  __syncthreads();
+  const T d_h = (T)hp.d_h, h_inv = (T)hp.h_inv, norm = (T)hp.norm;
+  const HomeCell<T> hc = make_home<T>(g);
+  for (int s = pb + threadIdx.x; s < pe; s += blockDim.x) {
+    const T px = sx[s], py = sy[s], pz = sz[s];
+    const int ix = home_cell_i(hc, px), iy = home_cell_i(hc, py), iz = home_cell_i(hc, pz);
+    const T dpcx = px * h_inv - ((T)ix + T(0.5)) * d_h;
+    const T dpcy = py * h_inv - ((T)iy + T(0.5)) * d_h;
+    const T dpcz = pz * h_inv - ((T)iz + T(0.5)) * d_h;
+    const int hx = wrap_cell(ix, n) - ox, hy = wrap_cell(iy, n) - oy, hz = wrap_cell(iz, n) - oz;
+    T vx = T(0), vy = T(0), vz = T(0);
+    const bool home_ok = (unsigned)(hx - tp.R) < (unsigned)tp.tx && (unsigned)(hy - tp.R) < (unsigned)tp.ty &&
+                         (unsigned)(hz - tp.R) < (unsigned)tp.tz;  // always true; keeps LDS indexing safe
+    for (int m = 0; home_ok && m < hp.ncol; ++m) {
+      const int4 c = s_cols[m];
+      const T xh = dpcx - (T)c.x * d_h;
+      const T yh = dpcy - (T)c.y * d_h;
+      const T r2ab = xh * xh + yh * yh;
+      if (r2ab > T(4)) continue;
+      const T *row = s_tile_pl + tp.lz * ((hy + c.y) + tp.ly * (hx + c.x)) + hz;
+      T zh = dpcz - (T)c.z * d_h;
+      for (int i3 = c.z; i3 <= c.w; ++i3) {
+        const T q_sq = r2ab + zh * zh;
+        if (q_sq <= T(4)) {
+          const T common = row[i3] * sph_grad_folded<T>(q_sq, norm);
+          vx += common * xh;
+          vy += common * yh;
+          vz += common * zh;
+        }
+        zh -= d_h;
+      }
+    }
+    const T normalize = (T)hp.normalize;
+    vx *= normalize;
+    vy *= normalize;
+    vz *= normalize;
+    if (rsd) vz += (T)hp.f1 * vz;
+    const long long p = sidx[s] & ~kSortFlagNoScatter;
+    V[p] = vx;
+    V[p + g.N] = vy;
+    V[p + 2 * g.N] = vz;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Specialisations for the standard stencil (h = d: the 81-cell hull of SPH_kernel_3D_cells_hull_1,
+// SPH_kernel.cpp:110-139) on 8 x 8 x 16 tiles with a 2-cell halo.  The hull and the LDS tile shape are compile-time
+// constants, so the column/cell loops unroll completely: the squared axis offsets are computed once per particle
+// (r^2 = X[a] + Y[b] + Z[c], one add per candidate instead of convert + fma + subtract + fma), every LDS access
+// has an immediate offset, and a rejected candidate costs add + compare + branch.  Same (particle, cell) pairs
+// and the same kernel evaluations as the generic kernels above; r^2 differs from theirs by rounding only.
+// ------------------------------------------------------------------------------------------------------
+// z half-width of hull column (a - 2, b - 2): -1 = not in the hull
+__host__ __device__ constexpr int hull81_zw(int a, int b) {
+  const int i1 = a < 2 ? 2 - a : a - 2, i2 = b < 2 ? 2 - b : b - 2;
+  return (i1 == 2 && i2 == 2) ? -1 : ((i1 == 2 || i2 == 2) ? 1 : 2);
+}
+
+template <typename T, int LY, int LZ>
+__global__ void __launch_bounds__(256)
+k_scatter_tile81(Geo g, SphPar sp, TilePar tp, int reorder, T *sx, T *sy, T *sz, int *sidx,
+                 const int *__restrict__ off, const int *__restrict__ tend, const int *__restrict__ woff,
+                 T *__restrict__ rho) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw_scatter81[];
+  double *s_tile_acc = reinterpret_cast<double *>(s_raw_scatter81);
+  int tile, pb, pe;
+  if (!tile_work(tp, off, tend, woff, tile, pb, pe)) return;
+  const int ncell = tp.lx * LY * LZ;
+  for (int c = threadIdx.x; c < ncell; c += blockDim.x) s_tile_acc[c] = 0.;
+  const T d = (T)g.d;
+  const HomeCell<T> hc = make_home<T>(g);
+  if (reorder) subsort_subcell<T>(reorder, pb, pe, hc.inv_d, sx, sy, sz, sidx);
+  __syncthreads();
+  const int tzi = tile % tp.ntz, tyi = (tile / tp.ntz) % tp.nty, txi = tile / (tp.ntz * tp.nty);
+  const int ox = txi * tp.tx - 2, oy = tyi * tp.ty - 2, oz = tzi * tp.tz - 2;  // global cell of LDS (0,0,0)
+  const int n = g.n;
+  const T r2_lim = (T)sp.r2_lim, h_inv = (T)sp.h_inv, w_norm = (T)sp.w_norm;
+  for (int s = pb + threadIdx.x; s < pe; s += blockDim.x) {
+    if (sidx[s] & kSortFlagNoScatter) continue;
+    const T x = sx[s], y = sy[s], z = sz[s];
+    const int ix = home_cell_i(hc, x), iy = home_cell_i(hc, y), iz = home_cell_i(hc, z);
+    const T ccx = ((T)ix + T(0.5)) * d, ccy = ((T)iy + T(0.5)) * d, ccz = ((T)iz + T(0.5)) * d;
+    const int hx = wrap_cell(ix, n) - ox, hy = wrap_cell(iy, n) - oy, hz = wrap_cell(iz, n) - oz;  // home cell in LDS coords
+    if ((unsigned)(hx - 2) >= (unsigned)tp.tx || (unsigned)(hy - 2) >= (unsigned)tp.ty ||
+        (unsigned)(hz - 2) >= (unsigned)tp.tz)
+      continue;  // cannot happen (binning and this kernel see the same stored position); keeps LDS indexing safe
+    T X[5], Y[5], Z[5];
+#pragma unroll
+    for (int a = 0; a < 5; a++) {
+      const T dx = x - (ccx + (T)(a - 2) * d), dy = y - (ccy + (T)(a - 2) * d), dz = z - (ccz + (T)(a - 2) * d);
+      X[a] = dx * dx;
+      Y[a] = dy * dy;
+      Z[a] = dz * dz;
+    }
+    double *corner = s_tile_acc + LZ * ((hy - 2) + LY * (hx - 2)) + (hz - 2);
+#pragma unroll
+    for (int a = 0; a < 5; a++) {
+#pragma unroll
+      for (int b = 0; b < 5; b++) {
+        const int zw = hull81_zw(a, b);  // folds after unrolling
+        if (zw < 0) continue;
+        const T r2ab = X[a] + Y[b];
+        if (r2ab > r2_lim) continue;
+        double *row = corner + LZ * (b + LY * a);
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+          if (c < 2 - zw || c > 2 + zw) continue;
+          const T r2 = r2ab + Z[c];
+          if (r2 <= r2_lim) {
+            const T q = (r2 * fast_rsqrt(r2 + tiny_pos<T>())) * h_inv;
+            if (q <= T(2)) atomic_add_r(row + c, (double)sph_w_folded<T>(q, w_norm));
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < ncell; c += blockDim.x) {
+    const double v = s_tile_acc[c];
+    if (v != 0.) {
+      const int cz = c % LZ, cy = (c / LZ) % LY, cx = c / (LZ * LY);
+      const int gx = (ox + cx + n) % n, gy = (oy + cy + n) % n, gz = (oz + cz + n) % n;
+      atomic_add_r(rho + gz + (long long)n * (gy + (long long)n * gx), (T)v);
+    }
+  }
+}
+
+template <typename T, int LY, int LZ>
+__global__ void __launch_bounds__(256)
+k_gather_tile81(Geo g, HullPar hp, TilePar tp, int rsd, const T *__restrict__ sx, const T *__restrict__ sy,
+                const T *__restrict__ sz, const int *__restrict__ sidx, const int *__restrict__ off,
+                const int *__restrict__ tend, const int *__restrict__ woff, const T *__restrict__ plike,
+                T *__restrict__ V) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw_gather81[];
+  T *s_tile_pl = reinterpret_cast<T *>(s_raw_gather81);
+  int tile, pb, pe;
+  if (!tile_work(tp, off, tend, woff, tile, pb, pe)) return;
+  const int ncell = tp.lx * LY * LZ;
+  const int n = g.n;
+  const int tzi = tile % tp.ntz, tyi = (tile / tp.ntz) % tp.nty, txi = tile / (tp.ntz * tp.nty);
+  const int ox = txi * tp.tx - 2, oy = tyi * tp.ty - 2, oz = tzi * tp.tz - 2;
+  for (int c = threadIdx.x; c < ncell; c += blockDim.x) {
+    const int cz = c % LZ, cy = (c / LZ) % LY, cx = c / (LZ * LY);
+    const int gx = (ox + cx + n) % n, gy = (oy + cy + n) % n, gz = (oz + cz + n) % n;
+    s_tile_pl[c] = plike[gz + (long long)n * (gy + (long long)n * gx)];
+  }
+  __syncthreads();
+  const T d_h = (T)hp.d_h, h_inv = (T)hp.h_inv, norm = (T)hp.norm;
+  const HomeCell<T> hc = make_home<T>(g);
+  for (int s = pb + threadIdx.x; s < pe; s += blockDim.x) {
+    const T px = sx[s], py = sy[s], pz = sz[s];
+    const int ix = home_cell_i(hc, px), iy = home_cell_i(hc, py), iz = home_cell_i(hc, pz);
+    const T dpcx = px * h_inv - ((T)ix + T(0.5)) * d_h;
+    const T dpcy = py * h_inv - ((T)iy + T(0.5)) * d_h;
+    const T dpcz = pz * h_inv - ((T)iz + T(0.5)) * d_h;
+    const int hx = wrap_cell(ix, n) - ox, hy = wrap_cell(iy, n) - oy, hz = wrap_cell(iz, n) - oz;
+    T vx = T(0), vy = T(0), vz = T(0);
+    const bool home_ok = (unsigned)(hx - 2) < (unsigned)tp.tx && (unsigned)(hy - 2) < (unsigned)tp.ty &&
+                         (unsigned)(hz - 2) < (unsigned)tp.tz;  // always true; keeps LDS indexing safe
+    if (home_ok) {
+      T xh[5], yh[5], zh[5], X[5], Y[5], Z[5];
+#pragma unroll
+      for (int a = 0; a < 5; a++) {
+        xh[a] = dpcx - (T)(a - 2) * d_h;
+        yh[a] = dpcy - (T)(a - 2) * d_h;
+        zh[a] = dpcz - (T)(a - 2) * d_h;
+        X[a] = xh[a] * xh[a];
+        Y[a] = yh[a] * yh[a];
+        Z[a] = zh[a] * zh[a];
+      }
+      const T *corner = s_tile_pl + LZ * ((hy - 2) + LY * (hx - 2)) + (hz - 2);
+#pragma unroll
+      for (int a = 0; a < 5; a++) {
+#pragma unroll
+        for (int b = 0; b < 5; b++) {
+          const int zw = hull81_zw(a, b);  // folds after unrolling
+          if (zw < 0) continue;
+          const T r2ab = X[a] + Y[b];
+          if (r2ab > T(4)) continue;
+          const T *row = corner + LZ * (b + LY * a);
+#pragma unroll
+          for (int c = 0; c < 5; c++) {
+            if (c < 2 - zw || c > 2 + zw) continue;
+            const T q_sq = r2ab + Z[c];
+            if (q_sq <= T(4)) {
+              const T common = row[c] * sph_grad_folded<T>(q_sq, norm);
+              vx += common * xh[a];
+              vy += common * yh[b];
+              vz += common * zh[c];
+            }
+          }
+        }
+      }
+    }
+    const T normalize = (T)hp.normalize;
+    vx *= normalize;
+    vy *= normalize;
+    vz *= normalize;
+    if (rsd) vz += (T)hp.f1 * vz;
+    const long long p = sidx[s] & ~kSortFlagNoScatter;
+    V[p] = vx;
+    V[p + g.N] = vy;
+    V[p + 2 * g.N] = vz;
+  }
+}
+
+}  // namespace bchmc
