@@ -545,7 +545,7 @@ struct Pipe {
         const int ncol = h->hull_exact ? h->hull_n : 0;
         // sub-cell ordering inside each work item: binary digits per axis (BCHMC_SUBSORT_BITS = 0 / 1 / 2)
         const char *sb = std::getenv("BCHMC_SUBSORT_BITS");
-        const int reorder = (h->tp.chunk != 2048) ? 0 : (sb ? std::min(std::max(atoi(sb), 0), 2) : 2);
+        const int reorder = (h->tp.chunk > 2048) ? 0 : (sb ? std::min(std::max(atoi(sb), 0), 2) : 2);
         if (h->std81)
           k_scatter_tile81<T, 12, 20><<<grid, 256, tile_lds(h, 0, sizeof(double)), h->stream>>>(
               h->g, sp, h->tp, reorder, R(h->sx), R(h->sy), R(h->sz), h->sidx, h->t_off, h->t_end, h->t_woff, R(h->rho));
@@ -1414,7 +1414,9 @@ int bchmc_create(const bchmc_config *cfg, bchmc_handle **out) {
         tp.lx = tp.tx + 2 * tp.R;
         tp.ly = tp.ty + 2 * tp.R;
         tp.lz = tp.tz + 2 * tp.R;
-        tp.chunk = 2048;
+        // particles per work item: 2048 fills the chip at 256^3 (8192+ items); smaller grids get smaller items
+        tp.chunk = g.N >= (1ll << 23) ? 2048 : (g.N >= (1ll << 20) ? 1024 : 256);
+        if (const char *ev = std::getenv("BCHMC_CHUNK")) tp.chunk = std::min(std::max(atoi(ev), 64), 2048);
         const size_t lds = (size_t)tp.lx * tp.ly * tp.lz * sizeof(double) + cols.size() * sizeof(int4) + 128;
         if (lds <= 64 * 1024 && g.N < (1ll << 30)) {
           h->tiled = true;

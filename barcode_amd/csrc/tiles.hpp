@@ -265,10 +265,10 @@ __device__ __forceinline__ bool tile_work(const TilePar &tp, const int *__restri
 // order): `bits` binary digits of the fractional cell coordinate per axis, octant digits most significant.  The 64
 // lanes of a wave then share most of the stencil cells that can pass the `r/h <= 2` test, and a wave pays for
 // every candidate ANY of its lanes needs (81 unsorted, ~51 with octants, fewer with 4 x 4 x 4 bins).  Pure
-// reordering: results do not depend on it.  Requires chunk == 256 * 8 and blockDim.x == 256.
+// reordering: results do not depend on it.  Requires chunk <= 256 * 8 and blockDim.x == 256.
 template <typename T>
 __device__ __forceinline__ void subsort_subcell(int bits, int pb, int pe, T inv_d, T *sx, T *sy, T *sz, int *sidx) {
-  constexpr int kPer = 8;  // tp.chunk == 256 * kPer
+  constexpr int kPer = 8;  // tp.chunk <= 256 * kPer
   __shared__ int hist[64], base[64];
   const int nb = 1 << (3 * bits);
   if (threadIdx.x < 64) hist[threadIdx.x] = 0;
