@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Soak run on one GPU: a long trajectory at 256^3 and a HamiltonianMC loop at 128^3 on the resident chain.
+Checks: finite state, no early stop, device memory stable, acceptance bookkeeping consistent."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from barcode_amd import hamil, inputs  # noqa: E402
+from barcode_amd.chains import EpsRing  # noqa: E402
+from barcode_amd.engine import Engine  # noqa: E402
+from barcode_amd.params import HamilParams  # noqa: E402
+
+
+def mock(p, e, f):
+    e.upload(signal_PS=f["signal_PS"], mass_f=f["mass_f"], nobs=np.zeros(p.N), window=np.ones(p.N), noise=np.ones(p.N))
+    e.forward(f["truth"], p.rsd_model)
+    dX = e.fetch("deltaX").reshape((p.Nx,) * 3)
+    window, noise, nobs = inputs.mock_observations(p, dX, delta_lag=f["truth"])
+    e.upload(window=window, noise=noise, nobs=nobs)
+    return dict(signal_PS=f["signal_PS"], mass_f=f["mass_f"], window=window, noise=noise, nobs=nobs)
+
+
+def main():
+    dev = torch.device("cuda", 0)
+    # ---- long trajectory
+    p = HamilParams(Nx=256, L=200.0, likelihood=1, rsd_model=1, sfmodel=2)
+    f = inputs.make_fields(p)
+    e = Engine(p)
+    mock(p, e, f)
+    q0 = torch.from_numpy(f["q0"].reshape(-1)).to(dev)
+    p0 = torch.from_numpy(f["p0"].reshape(-1)).to(dev)
+    q1, p1 = torch.empty_like(q0), torch.empty_like(p0)
+    eps = 0.5 * p.eps_heuristic()
+    free0 = torch.cuda.mem_get_info()[0]
+    t0 = time.perf_counter()
+    e.leapfrog_device(q0, p0, q1, p1, eps, 1000)
+    done = e.steps_done()
+    dt = time.perf_counter() - t0
+    en0, en1 = e.energies_device(q0, p0), e.energies_device(q1, p1)
+    free1 = torch.cuda.mem_get_info()[0]
+    print("256^3: 1000 steps in %.2f s (%.1f steps/s), done %d, finite %s, H %.6e -> %.6e (dH %.3e), device memory delta %.1f MB"
+          % (dt, 1000 / dt, done, bool(torch.isfinite(q1).all() and torch.isfinite(p1).all()), en0.sum(), en1.sum(),
+             en1.sum() - en0.sum(), (free0 - free1) / 1e6))
+    assert done == 1000
+    e.close()
+    # ---- sampler loop
+    p = HamilParams(Nx=128, L=200.0, likelihood=1, rsd_model=1, sfmodel=2)
+    f = inputs.make_fields(p)
+    hd = hamil.HamilData(p, N_eps_fac=8.0, eps_fac=2.0 * p.eps_heuristic())
+    mock(p, hd.engine, f)
+    hd.engine.chain_set_state(f["q0"])
+    rng = np.random.default_rng(7)
+    ring = EpsRing()
+    n_acc = n_att = 0
+    for sample in range(6):
+        log = hamil.HamiltonianMC(hd, rng.random, seed=11, itmax=50, ring=ring)
+        n_att += len(log)
+        n_acc += sum(r["accepted"] for r in log)
+        r = log[-1]
+        print("sample %d: %d attempt(s), last dH %.3e, eps %.3e, Neps %d, accepted %s" %
+              (sample, len(log), r["dH"], r["epsilon"], r["Neps"], r["accepted"]))
+    km, pw = hd.engine.measure_spectrum(None, 50)
+    print("acceptance %d/%d; resident-state spectrum bins with power: %d" % (n_acc, n_att, int((pw > 0).sum())))
+    assert n_acc == 6 and np.isfinite(pw).all()
+    hd.engine.close()
+
+
+if __name__ == "__main__":
+    main()
