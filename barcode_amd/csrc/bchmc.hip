@@ -847,7 +847,7 @@ struct Pipe {
       case 32: BCHMC_LAUNCH_X(NT_SMALL, 4); break;
       case 64: BCHMC_LAUNCH_X(NT_SMALL, 8); break;
       case 128: BCHMC_LAUNCH_X(NT_BIG, 4); break;
-      case 256: BCHMC_LAUNCH_X(NT_BIG, 8); break;
+      case 256: BCHMC_LAUNCH_X(2 * NT_BIG, 4); break;  // 4 elements per thread: a little faster than 8 x NT_BIG
       case 512: BCHMC_LAUNCH_X(2 * NT_BIG, 8); break;
       default: return h->fail(BCHMC_ERR_STATE, "planes mode is not available for n = %d", n);
     }
