@@ -503,14 +503,16 @@ struct Pipe {
   // C2R of the three displacement components, mass assignment, sum of rho.  Lag2Eul.cc:90-131 / 363-423.
   static int forward_rest(bchmc_handle *h, int rsd) {
     if (rsd && !h->c.planepar) return h->fail(BCHMC_ERR_RSD_NOT_PLANEPAR, "non-plane-parallel RSD is not implemented");
-    CHK(fft_exec(h, h->planes_c2r ? h->c2r2d : h->c2r3, h->Ck, h->psi, BCHMC_K_FFT_C2R));
     if (h->disp_alpt) {
+      // ALPT: transform into V (free until the gather) and let cellboundcomp write the displacement proper
       if (rsd) return h->fail(BCHMC_ERR_STATE, "ALPT displacement with the RSD routine");
+      CHK(fft_exec(h, h->c2r3, h->Ck, h->V, BCHMC_K_FFT_C2R));
       ProfScope ps(h, BCHMC_K_OTHER);
-      k_alpt_cellbound<T><<<nblk_stride(h->g.N), 256, 0, h->stream>>>(h->g, R(h->psi), R(h->V));
+      k_alpt_cellbound<T><<<nblk_stride(h->g.N), 256, 0, h->stream>>>(h->g, R(h->V), R(h->psi));
       HIPCHK(hipGetLastError());
-      HIPCHK(hipMemcpyAsync(h->psi, h->V, 3 * (size_t)h->g.N * sizeof(T), hipMemcpyDeviceToDevice, h->stream));
       h->disp_alpt = false;
+    } else {
+      CHK(fft_exec(h, h->planes_c2r ? h->c2r2d : h->c2r3, h->Ck, h->psi, BCHMC_K_FFT_C2R));
     }
     h->sorted_valid = false;
     const PosPar pp = make_pos(h, rsd);
