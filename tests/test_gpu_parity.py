@@ -337,6 +337,26 @@ def test_padded_half_complex_rows(monkeypatch, kw):
     e.close()
 
 
+@pytest.mark.parametrize("kw", [dict(likelihood=0, rsd_model=0), dict(likelihood=2, rsd_model=0),
+                                dict(likelihood=1, rsd_model=0, deltaQ_factor=0.9, grad_psi_prior_factor=0.5,
+                                     grad_psi_likeli_factor=2.0, correct_delta=0)],
+                         ids=["poisson", "lognormal", "factors"])
+def test_planes_mode_other_likelihoods(monkeypatch, kw):
+    """Planes mode only changes how V^ reaches the boundary arithmetic: other likelihoods and the test factors."""
+    monkeypatch.setenv("BCHMC_FFT_PAD", "1")
+    c = Case(Nx=32, **kw)
+    e = c.engine()
+    q1o, p1o, _ = c.oracle.Hamiltonian_EoM(c.q0, c.p0, c.eps, 5)
+    q1, p1, done = e.leapfrog(c.q0, c.p0, c.eps, 5)
+    assert done == 5 and rel_l2(q1, q1o) < TOL_TRAJ_10 and rel_l2(p1, p1o) < TOL_TRAJ_10
+    e.chain_set_state(c.q0)
+    e.chain_set_momenta(c.p0)
+    dH, terms, _ = e.chain_attempt(c.eps, 5)
+    dHo, to = c.oracle.delta_Hamiltonian(c.q0, c.p0, q1o, p1o)
+    assert np.all(np.abs(terms - to) <= 1e-8 * np.abs(to).max())
+    e.close()
+
+
 @pytest.mark.parametrize("nx,precision", [(32, 0), (32, 1), (64, 0)], ids=["n32_fp64", "n32_fp32", "n64_fp64"])
 def test_planes_mode_step_boundary(monkeypatch, nx, precision):
     """Interior step boundaries in "planes" mode (2-D rocFFT transforms of the (y, z) planes, the x passes fused into
