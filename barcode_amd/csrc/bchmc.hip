@@ -533,7 +533,7 @@ struct Pipe {
       }
       k_bin<T, false><<<fb_grid, 256, 0, h->stream>>>(h->g, pp, sp, h->tp, nbricks, R(h->psi), cnt2, ovf, h->t_rank,
                                                       R(h->sx), R(h->sy), R(h->sz), h->sidx, R(h->V));
-      k_scan_tiles<<<1, 1024, 0, h->stream>>>(h->tp, cnt1, cnt2, ovf, h->t_off, h->t_end, h->t_woff);
+      k_scan_tiles<<<(nt + 1023) / 1024, 1024, 0, h->stream>>>(h->tp, cnt1, cnt2, ovf, h->t_off, h->t_end, h->t_woff);
       k_reorder<T><<<fb_grid, 256, 0, h->stream>>>(h->g, pp, nbricks, R(h->psi), h->t_rank, h->t_off, ovf, R(h->sx),
                                                    R(h->sy), R(h->sz), h->sidx);
       HIPCHK(hipGetLastError());
