@@ -543,6 +543,8 @@ struct Pipe {
       ProfScope ps(h, BCHMC_K_SCATTER);
       HIPCHK(hipMemsetAsync(h->rho, 0, h->g.N * sizeof(T), h->stream));
       if (h->c.mk == 3 && h->tiled) {
+        // the tile kernels also leave sum(rho) in rho_part (partial sums of what they flush): no pass over rho
+        HIPCHK(hipMemsetAsync(h->rho_part, 0, kRedBlocks * sizeof(double), h->stream));
         const int grid = h->tp.ntiles + (int)(h->g.N / h->tp.chunk) + 1;  // upper bound on (tile, chunk) work items
         const int ncol = h->hull_exact ? h->hull_n : 0;
         // sub-cell ordering inside each work item: binary digits per axis (BCHMC_SUBSORT_BITS = 0 / 1 / 2)
@@ -550,11 +552,11 @@ struct Pipe {
         const int reorder = (h->tp.chunk > 2048) ? 0 : (sb ? std::min(std::max(atoi(sb), 0), 2) : 2);
         if (h->std81)
           k_scatter_tile81<T, 12, 20><<<grid, 256, tile_lds(h, 0, sizeof(double)), h->stream>>>(
-              h->g, sp, h->tp, reorder, R(h->sx), R(h->sy), R(h->sz), h->sidx, h->t_off, h->t_end, h->t_woff, R(h->rho));
+              h->g, sp, h->tp, reorder, R(h->sx), R(h->sy), R(h->sz), h->sidx, h->t_off, h->t_end, h->t_woff, R(h->rho), h->rho_part);
         else
           k_scatter_tile<T><<<grid, 256, tile_lds(h, ncol, sizeof(double)), h->stream>>>(
               h->g, sp, h->tp, h->hull, ncol, reorder, R(h->sx), R(h->sy), R(h->sz), h->sidx, h->t_off, h->t_end,
-              h->t_woff, R(h->rho));
+              h->t_woff, R(h->rho), h->rho_part);
       } else if (h->c.mk == 3) {
         k_scatter_sph<T><<<nblk_full(h->g.N), 256, 0, h->stream>>>(h->g, pp, sp, R(h->psi), R(h->rho));
       } else if (h->c.mk >= 0 && h->c.mk <= 2) {
@@ -564,7 +566,7 @@ struct Pipe {
       }
       HIPCHK(hipGetLastError());
     }
-    {
+    if (!(h->c.mk == 3 && h->tiled)) {
       ProfScope ps(h, BCHMC_K_MEAN_PARTIAL);
       k_sum<T><<<kRedBlocks, 256, 0, h->stream>>>(R(h->rho), h->g.N, h->rho_part);
       HIPCHK(hipGetLastError());

@@ -352,7 +352,7 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 k_scatter_tile(Geo g, SphPar sp, TilePar tp, const int4 *__restrict__ cols, int ncol, int reorder, T *sx, T *sy, T *sz,
                int *sidx, const int *__restrict__ off, const int *__restrict__ tend, const int *__restrict__ woff,
-               T *__restrict__ rho) {
+               T *__restrict__ rho, double *__restrict__ rho_part) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw_scatter[];
   double *s_tile_acc = reinterpret_cast<double *>(s_raw_scatter);  // accumulate in double also for float fields
   int tile, pb, pe;
@@ -418,14 +418,19 @@ k_scatter_tile(Geo g, SphPar sp, TilePar tp, const int4 *__restrict__ cols, int 
     }
   }
   __syncthreads();
+  double flushed = 0.;  // sum of everything this work item adds to rho: the mean density needs no pass over rho
   for (int c = threadIdx.x; c < ncell; c += blockDim.x) {
     const double v = s_tile_acc[c];
     if (v != 0.) {
+      flushed += (double)(T)v;
       const int cz = c % tp.lz, cy = (c / tp.lz) % tp.ly, cx = c / (tp.lz * tp.ly);
       const int gx = (ox + cx + n) % n, gy = (oy + cy + n) % n, gz = (oz + cz + n) % n;
       atomic_add_r(rho + gz + (long long)n * (gy + (long long)n * gx), (T)v);
     }
   }
+  __shared__ double s_red_flush[4];
+  flushed = block_sum(flushed, s_red_flush);
+  if (threadIdx.x == 0 && flushed != 0.) atomic_add_r(rho_part + (blockIdx.x & (kRedBlocks - 1)), flushed);
 }
 
 // likelihood_calc_V_SPH on sorted particles: part_like tile + halo staged in LDS.
@@ -512,7 +517,7 @@ template <typename T, int LY, int LZ>
 __global__ void __launch_bounds__(256)
 k_scatter_tile81(Geo g, SphPar sp, TilePar tp, int reorder, T *sx, T *sy, T *sz, int *sidx,
                  const int *__restrict__ off, const int *__restrict__ tend, const int *__restrict__ woff,
-                 T *__restrict__ rho) {
+                 T *__restrict__ rho, double *__restrict__ rho_part) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw_scatter81[];
   double *s_tile_acc = reinterpret_cast<double *>(s_raw_scatter81);
   int tile, pb, pe;
@@ -567,14 +572,19 @@ k_scatter_tile81(Geo g, SphPar sp, TilePar tp, int reorder, T *sx, T *sy, T *sz,
     }
   }
   __syncthreads();
+  double flushed = 0.;  // sum of everything this work item adds to rho: the mean density needs no pass over rho
   for (int c = threadIdx.x; c < ncell; c += blockDim.x) {
     const double v = s_tile_acc[c];
     if (v != 0.) {
+      flushed += (double)(T)v;
       const int cz = c % LZ, cy = (c / LZ) % LY, cx = c / (LZ * LY);
       const int gx = (ox + cx + n) % n, gy = (oy + cy + n) % n, gz = (oz + cz + n) % n;
       atomic_add_r(rho + gz + (long long)n * (gy + (long long)n * gx), (T)v);
     }
   }
+  __shared__ double s_red_flush[4];
+  flushed = block_sum(flushed, s_red_flush);
+  if (threadIdx.x == 0 && flushed != 0.) atomic_add_r(rho_part + (blockIdx.x & (kRedBlocks - 1)), flushed);
 }
 
 template <typename T, int LY, int LZ>
