@@ -83,6 +83,25 @@ def test_256_reversibility(big):
     assert rel_l2(-p2, f["p0"]) < 1e-8
 
 
+def test_256_planes_mode_is_the_3d_plan_trajectory(big, monkeypatch):
+    """At the BASELINE size the interior step boundaries run in planes mode (2-D rocFFT plans + k_step_boundary_x with
+    512-thread workgroups); the same trajectory with the batched 3-D plans (BCHMC_NO_PLANES=1) must agree to the
+    scatter's summation noise.  Beyond the oracle's reach; the small-grid variants of both paths are checked against
+    the oracle in tests/test_gpu_parity.py."""
+    from barcode_amd.engine import Engine
+    p, f, e, dX = big
+    eps = 0.5 * p.eps_heuristic()
+    q1, p1, done = e.leapfrog(f["q0"], f["p0"], eps, 6)
+    monkeypatch.setenv("BCHMC_NO_PLANES", "1")
+    window, noise, nobs = inputs.mock_observations(p, dX)
+    e2 = Engine(p)
+    e2.upload(signal_PS=f["signal_PS"], mass_f=f["mass_f"], window=window, noise=noise, nobs=nobs)
+    q2, p2, done2 = e2.leapfrog(f["q0"], f["p0"], eps, 6)
+    e2.close()
+    assert done == done2 == 6
+    assert rel_l2(q1, q2) < 1e-13 and rel_l2(p1, p2) < 1e-12
+
+
 def test_256_energy_terms_against_real_space_evaluation(big):
     """The engine evaluates 1/2 x^T A x by Parseval in k-space; compare with the reference's real-space form
     0.5 * sum(x * IFFT[w FFT x]) (HMC.cc:101-115, gaussian.cpp:24-32) computed with numpy, and the Gaussian
