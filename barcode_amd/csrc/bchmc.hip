@@ -98,8 +98,8 @@ struct bchmc_handle {
   double alpt_wtot = 0.;     // kernelcomp's normalisation (sum of the real-space kernel), computed on first use
   bool std81 = false;  // standard 81-cell hull on 8 x 8 x 16 tiles with halo 2: fully unrolled scatter/gather kernels
   TilePar tp{};
-  int *t_cnt = nullptr, *t_off = nullptr, *t_woff = nullptr;  // 2 * ntiles + 1 (direct counts, fallback counts, overflow flag), ntiles, ntiles+1
-  int *t_end = nullptr;                                        // ntiles
+  int *t_cnt = nullptr, *t_woff = nullptr;   // 2 ntiles + 2 (one-pass counts, fallback counts, overflow flags), ntiles + 1
+  long long *t_off = nullptr, *t_end = nullptr;  // ntiles each: record range of every tile (ntiles * cap can pass 2^31)
   int2 *t_rank = nullptr;                                      // N
   void *sx = nullptr, *sy = nullptr, *sz = nullptr;            // N each: sorted positions
   int *sidx = nullptr;                                         // N: original index | flags
@@ -330,7 +330,7 @@ int grow_sort_slots(bchmc_handle *h) {
   const long long cap = 2ll * h->tp.cap;
   h->sorted_valid = false;
   const long long mean_occ = (long long)h->tp.tx * h->tp.ty * h->tp.tz;
-  if (cap * h->tp.ntiles >= (1ll << 31) || cap > 32 * std::max<long long>(mean_occ, 64)) {
+  if (cap > 32 * std::max<long long>(mean_occ, 64)) {
     // a tile holding more than 32x the mean is a pathological field: keep the two-pass sort instead of more memory
     h->sort_direct = false;
     return BCHMC_OK;
@@ -1439,7 +1439,7 @@ int bchmc_create(const bchmc_config *cfg, bchmc_handle **out) {
           long long cap = std::max<long long>(8 * mean_occ, 64);
           if (const char *ev = std::getenv("BCHMC_SORT_CAP")) cap = atoll(ev);
           size_t nrec = N;
-          h->sort_direct = cap > 0 && cap * tp.ntiles < (1ll << 31);
+          h->sort_direct = cap > 0 && cap < (1ll << 30);  // record offsets are 64-bit, per-tile ranges 32-bit
           if (h->sort_direct) {
             tp.cap = (int)cap;
             nrec = std::max<size_t>(N, (size_t)cap * tp.ntiles);

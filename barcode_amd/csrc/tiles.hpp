@@ -203,7 +203,8 @@ __device__ __forceinline__ int2 block_exclusive_scan2_1024(int a, int b, int2 *w
 
 __global__ void __launch_bounds__(1024)
 k_scan_tiles(TilePar tp, const int *__restrict__ cnt_direct, const int *__restrict__ cnt_fallback,
-             const int *__restrict__ ovf, int *__restrict__ off, int *__restrict__ tend, int *__restrict__ woff) {
+             const int *__restrict__ ovf, long long *__restrict__ off, long long *__restrict__ tend,
+             int *__restrict__ woff) {
   // One tile per thread, ceil(ntiles / 1024) workgroups.  A workgroup first sums the counts of all tiles before its
   // own range (coalesced reads, at most 4 * ntiles bytes), then scans its 1024 tiles: every load and store is
   // coalesced, which a single workgroup striding over all tiles was not (33 us for 16384 tiles).
@@ -232,7 +233,7 @@ k_scan_tiles(TilePar tp, const int *__restrict__ cnt_direct, const int *__restri
   const int2 ex = block_exclusive_scan2_1024(c, items(c), wtot);
   const int ea = base.x + ex.x, eb = base.y + ex.y;
   if (t < T) {
-    const int o = direct ? t * tp.cap : ea;  // one-pass layout: fixed slots per tile; fallback: packed
+    const long long o = direct ? (long long)t * tp.cap : (long long)ea;  // one-pass: fixed slots per tile; fallback: packed
     off[t] = o;
     tend[t] = o + c;
     woff[t] = eb;
@@ -244,7 +245,7 @@ k_scan_tiles(TilePar tp, const int *__restrict__ cnt_direct, const int *__restri
 template <typename T>
 __global__ void __launch_bounds__(256)
 k_reorder(Geo g, PosPar pp, int nbricks, const T *__restrict__ psi, const int2 *__restrict__ tile_rank,
-          const int *__restrict__ off, const int *__restrict__ ovf, T *__restrict__ sx, T *__restrict__ sy,
+          const long long *__restrict__ off, const int *__restrict__ ovf, T *__restrict__ sx, T *__restrict__ sy,
           T *__restrict__ sz, int *__restrict__ sidx) {
   if (!*ovf) return;  // the one-pass binning succeeded
   for (int brick = blockIdx.x; brick < nbricks; brick += gridDim.x) {
@@ -255,7 +256,7 @@ k_reorder(Geo g, PosPar pp, int nbricks, const T *__restrict__ psi, const int2 *
     if (tr.x < 0) continue;
     T x, y, z;
     particle_pos<T>(pp, i, j, k, psi[p], psi[p + g.N], psi[p + 2 * g.N], x, y, z);
-    const int slot = off[tr.x] + (tr.y & ~kSortFlagNoScatter);
+    const long long slot = off[tr.x] + (tr.y & ~kSortFlagNoScatter);
     sx[slot] = x;
     sy[slot] = y;
     sz[slot] = z;
@@ -264,12 +265,16 @@ k_reorder(Geo g, PosPar pp, int nbricks, const T *__restrict__ psi, const int2 *
 }
 
 // Work item -> (tile, particle range).  Returns false when this workgroup has nothing to do.
-__device__ __forceinline__ bool tile_work(const TilePar &tp, const int *__restrict__ off, const int *__restrict__ tend,
-                                          const int *__restrict__ woff, int &tile, int &p_begin, int &p_end) {
+__device__ __forceinline__ bool tile_work(const TilePar &tp, const long long *__restrict__ off,
+                                          const long long *__restrict__ tend, const int *__restrict__ woff, int &tile,
+                                          long long &base, int &p_begin, int &p_end) {
+  // base = first record slot of the tile (64-bit: ntiles * cap may exceed 2^31), [p_begin, p_end) relative to it
   __shared__ int s_tile, s_b, s_e;
+  __shared__ long long s_base;
   if (threadIdx.x == 0) {
     const int w = blockIdx.x;
     int t = -1, b = 0, e = 0;
+    long long o = 0;
     if (w < woff[tp.ntiles]) {
       int lo = 0, hi = tp.ntiles;  // last t with woff[t] <= w
       while (hi - lo > 1) {
@@ -277,17 +282,20 @@ __device__ __forceinline__ bool tile_work(const TilePar &tp, const int *__restri
         if (woff[mid] <= w) lo = mid; else hi = mid;
       }
       t = lo;
-      b = off[t] + (w - woff[t]) * tp.chunk;
-      e = min(b + tp.chunk, tend[t]);
+      o = off[t];
+      b = (w - woff[t]) * tp.chunk;
+      e = min(b + tp.chunk, (int)(tend[t] - o));
     }
     s_tile = t;
     s_b = b;
     s_e = e;
+    s_base = o;
   }
   __syncthreads();
   tile = s_tile;
   p_begin = s_b;
   p_end = s_e;
+  base = s_base;
   return tile >= 0;
 }
 
@@ -351,12 +359,17 @@ __device__ __forceinline__ void subsort_subcell(int bits, int pb, int pe, T inv_
 template <typename T>
 __global__ void __launch_bounds__(256)
 k_scatter_tile(Geo g, SphPar sp, TilePar tp, const int4 *__restrict__ cols, int ncol, int reorder, T *sx, T *sy, T *sz,
-               int *sidx, const int *__restrict__ off, const int *__restrict__ tend, const int *__restrict__ woff,
+               int *sidx, const long long *__restrict__ off, const long long *__restrict__ tend, const int *__restrict__ woff,
                T *__restrict__ rho, double *__restrict__ rho_part) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw_scatter[];
   double *s_tile_acc = reinterpret_cast<double *>(s_raw_scatter);  // accumulate in double also for float fields
   int tile, pb, pe;
-  if (!tile_work(tp, off, tend, woff, tile, pb, pe)) return;
+  long long rec0;
+  if (!tile_work(tp, off, tend, woff, tile, rec0, pb, pe)) return;
+  sx += rec0;  // this tile's record slots; pb, pe are relative to them
+  sy += rec0;
+  sz += rec0;
+  sidx += rec0;
   const int ncell = tp.lx * tp.ly * tp.lz;
   int4 *s_cols = reinterpret_cast<int4 *>(s_raw_scatter + (((size_t)ncell * sizeof(double) + 15) & ~(size_t)15));
   for (int m = threadIdx.x; m < ncol; m += blockDim.x) s_cols[m] = cols[m];
@@ -437,13 +450,18 @@ k_scatter_tile(Geo g, SphPar sp, TilePar tp, const int4 *__restrict__ cols, int 
 template <typename T>
 __global__ void __launch_bounds__(256)
 k_gather_tile(Geo g, HullPar hp, TilePar tp, int rsd, const T *__restrict__ sx, const T *__restrict__ sy,
-              const T *__restrict__ sz, const int *__restrict__ sidx, const int *__restrict__ off,
-              const int *__restrict__ tend, const int *__restrict__ woff, const T *__restrict__ plike,
+              const T *__restrict__ sz, const int *__restrict__ sidx, const long long *__restrict__ off,
+              const long long *__restrict__ tend, const int *__restrict__ woff, const T *__restrict__ plike,
               T *__restrict__ V) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw_gather[];
   T *s_tile_pl = reinterpret_cast<T *>(s_raw_gather);
   int tile, pb, pe;
-  if (!tile_work(tp, off, tend, woff, tile, pb, pe)) return;
+  long long rec0;
+  if (!tile_work(tp, off, tend, woff, tile, rec0, pb, pe)) return;
+  sx += rec0;  // this tile's record slots; pb, pe are relative to them
+  sy += rec0;
+  sz += rec0;
+  sidx += rec0;
   const int ncell = tp.lx * tp.ly * tp.lz;
   int4 *s_cols = reinterpret_cast<int4 *>(s_raw_gather + (((size_t)ncell * sizeof(T) + 15) & ~(size_t)15));
   for (int m = threadIdx.x; m < hp.ncol; m += blockDim.x) s_cols[m] = hp.cols[m];
@@ -516,12 +534,17 @@ __host__ __device__ constexpr int hull81_zw(int a, int b) {
 template <typename T, int LY, int LZ>
 __global__ void __launch_bounds__(256)
 k_scatter_tile81(Geo g, SphPar sp, TilePar tp, int reorder, T *sx, T *sy, T *sz, int *sidx,
-                 const int *__restrict__ off, const int *__restrict__ tend, const int *__restrict__ woff,
+                 const long long *__restrict__ off, const long long *__restrict__ tend, const int *__restrict__ woff,
                  T *__restrict__ rho, double *__restrict__ rho_part) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw_scatter81[];
   double *s_tile_acc = reinterpret_cast<double *>(s_raw_scatter81);
   int tile, pb, pe;
-  if (!tile_work(tp, off, tend, woff, tile, pb, pe)) return;
+  long long rec0;
+  if (!tile_work(tp, off, tend, woff, tile, rec0, pb, pe)) return;
+  sx += rec0;  // this tile's record slots; pb, pe are relative to them
+  sy += rec0;
+  sz += rec0;
+  sidx += rec0;
   const int ncell = tp.lx * LY * LZ;
   for (int c = threadIdx.x; c < ncell; c += blockDim.x) s_tile_acc[c] = 0.;
   const T d = (T)g.d;
@@ -590,13 +613,18 @@ k_scatter_tile81(Geo g, SphPar sp, TilePar tp, int reorder, T *sx, T *sy, T *sz,
 template <typename T, int LY, int LZ>
 __global__ void __launch_bounds__(256)
 k_gather_tile81(Geo g, HullPar hp, TilePar tp, int rsd, const T *__restrict__ sx, const T *__restrict__ sy,
-                const T *__restrict__ sz, const int *__restrict__ sidx, const int *__restrict__ off,
-                const int *__restrict__ tend, const int *__restrict__ woff, const T *__restrict__ plike,
+                const T *__restrict__ sz, const int *__restrict__ sidx, const long long *__restrict__ off,
+                const long long *__restrict__ tend, const int *__restrict__ woff, const T *__restrict__ plike,
                 T *__restrict__ V) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw_gather81[];
   T *s_tile_pl = reinterpret_cast<T *>(s_raw_gather81);
   int tile, pb, pe;
-  if (!tile_work(tp, off, tend, woff, tile, pb, pe)) return;
+  long long rec0;
+  if (!tile_work(tp, off, tend, woff, tile, rec0, pb, pe)) return;
+  sx += rec0;  // this tile's record slots; pb, pe are relative to them
+  sy += rec0;
+  sz += rec0;
+  sidx += rec0;
   const int ncell = tp.lx * LY * LZ;
   const int n = g.n;
   const int tzi = tile % tp.ntz, tyi = (tile / tp.ntz) % tp.nty, txi = tile / (tp.ntz * tp.nty);
