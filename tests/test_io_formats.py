@@ -45,3 +45,42 @@ def test_dump_measured_spec_format(tmp_path):
     assert fn.endswith("powSpecit12.dat")
     dump_measured_spec([0.0, 0.0314159265, 0.25, 1.5], [5.0, 1234.56789, 0.0, 1e-5], fn)
     assert open(fn).read() == "0.0314159   1234.57\n1.5   1e-05\n"
+
+
+def test_input_par_reader_against_the_reference_fixture():
+    """The REQUIREs of the reference's own test (test/parameter_input_file.cpp:21-46) on its own fixture
+    (test/data/input.par, copied as tests/golden/reference_test_input.par)."""
+    import os
+    from barcode_amd.input_par import parameter_inifile
+    from tests.util import GOLDEN_DIR
+    params = parameter_inifile(os.path.join(GOLDEN_DIR, "reference_test_input.par"))
+    assert params.find(bool, "bool_true") is True
+    assert params.find(bool, "bool_false") is False
+    assert params.find(bool, "bool_comment") is False
+    for key in ("zero", "zero_comment"):
+        assert params.find(int, key) == 0 and params.find(float, key) == 0.0
+    assert params.find(float, "float_one") == 1.0
+    assert params.find(float, "float_minus") == -1.2
+    assert params.find(str, "string") == "hello_no_spaces_please"
+    assert params.find(str, "string_comment") == "stuff"
+
+
+def test_hamil_params_from_the_reference_input_par_template():
+    """data/input.par (the template main.cc reads) -> the scalars of the leapfrog path (init_par.cc:52-186, 293-334)."""
+    import os
+    from barcode_amd.input_par import hamil_params
+    from tests.util import GOLDEN_DIR
+    p = hamil_params(os.path.join(GOLDEN_DIR, "reference_template_input.par"))
+    assert (p.Nx, p.L, p.mk, p.calc_h, p.likelihood, p.prior, p.sfmodel, p.rsd_model, p.mass_type) == \
+        (64, 200.0, 3, 2, 1, 0, 1, 0, 1)
+    assert (p.xobs, p.yobs, p.zobs, p.planepar, p.periodic) == (90.0, 90.0, 90.0, 1, 1)
+    assert (p.kth, p.correct_delta, p.div_dH_by_N, p.particle_kernel_h_rel) == (4.0, 1, 0, 1.0)
+    assert (p.grad_psi_prior_factor, p.grad_psi_likeli_factor, p.deltaQ_factor) == (1.0, 1.0, 1.0)
+    assert (p.sigma_min, p.delta_min, p.ascale) == (1.0, -0.999, 1.0)
+    assert p.particle_kernel_h == 200.0 / 64
+    # the dataclass defaults ARE this template
+    from barcode_amd.params import HamilParams
+    d = HamilParams()
+    for k in ("Nx", "L", "mk", "calc_h", "likelihood", "sfmodel", "rsd_model", "mass_type", "kth", "xobs", "planepar",
+              "periodic", "correct_delta", "div_dH_by_N", "deltaQ_factor", "sigma_min", "delta_min", "ascale"):
+        assert getattr(d, k) == getattr(p, k), k
