@@ -32,6 +32,9 @@ CASES = {
     "gauss_calch3_rsd_8": dict(Nx=8, likelihood=1, rsd_model=1, calc_h=3),
     "gauss_cic_calch1_8": dict(Nx=8, likelihood=1, rsd_model=0, calc_h=1, mk=1),
     "gauss_alpt_8": dict(Nx=8, likelihood=1, rsd_model=0, sfmodel=2),  # ALPT forward model
+    "poisson_calch3_8": dict(Nx=8, likelihood=0, rsd_model=0, calc_h=3),
+    "poisson_ngp_calch1_8": dict(Nx=8, likelihood=0, rsd_model=0, calc_h=1, mk=0),
+    "gauss_tsc_calch1_rsd_8": dict(Nx=8, likelihood=1, rsd_model=1, calc_h=1, mk=2),
 }
 NEPS = 10
 
