@@ -1271,7 +1271,28 @@ int bchmc_create(const bchmc_config *cfg, bchmc_handle **out) {
 
   auto run = [&]() -> int {
     HIPCHK(hipSetDevice(cfg->device));
-    HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    if (const char *cm = std::getenv("BCHMC_CU_MASK")) {
+      // experiment: restrict this handle's stream to a subset of the CUs (two chains per GPU on disjoint halves).
+      // "lo" / "hi": first / second half of the mask bits; "even" / "odd": alternating groups of 32 bits (XCD-sized)
+      hipDeviceProp_t prop;
+      HIPCHK(hipGetDeviceProperties(&prop, cfg->device));
+      const int ncu = prop.multiProcessorCount, words = (ncu + 31) / 32;
+      std::vector<uint32_t> mask(words, 0u);
+      const std::string mode(cm);
+      for (int cu = 0; cu < ncu; cu++) {
+        bool on = true;
+        if (mode == "lo") on = cu < ncu / 2;
+        else if (mode == "hi") on = cu >= ncu / 2;
+        else if (mode == "even") on = ((cu / 32) & 1) == 0;
+        else if (mode == "odd") on = ((cu / 32) & 1) == 1;
+        else if (mode == "evencu") on = (cu & 1) == 0;
+        else if (mode == "oddcu") on = (cu & 1) == 1;
+        if (on) mask[cu / 32] |= 1u << (cu % 32);
+      }
+      HIPCHK(hipExtStreamCreateWithCUMask(&h->stream, (uint32_t)words, mask.data()));
+    } else {
+      HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    }
     {
       std::lock_guard<std::mutex> lk(g_rocfft_mu);
       if (g_rocfft_users++ == 0) FFTCHK(rocfft_setup());
