@@ -16,8 +16,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _lib = None
 
 SHIM_EXPORTS = ("bchmc_shim_Hamiltonian_EoM", "bchmc_shim_delta_Hamiltonian", "bchmc_shim_gradient_psi",
-                "bchmc_shim_measure_spectrum", "bchmc_shim_release", "bchmc_shim_sizeof_view",
-                "bchmc_shim_sizeof_numerical")
+                "bchmc_shim_measure_spectrum", "bchmc_shim_chain_set_state", "bchmc_shim_chain_get_state",
+                "bchmc_shim_HamiltonianMC", "bchmc_shim_release", "bchmc_shim_sizeof_view",
+                "bchmc_shim_sizeof_numerical", "bchmc_shim_sizeof_attempt_log")
 
 _dp = C.POINTER(C.c_double)
 
@@ -54,6 +55,15 @@ class HamilView(C.Structure):
     ]
 
 
+class AttemptLog(C.Structure):
+    """bchmc_shim::AttemptLog: one row of performance_log.txt (HMC.cc:40-60)."""
+    _fields_ = [("accepted", C.c_bool), ("epsilon", C.c_double), ("Neps", C.c_ulong), ("steps_done", C.c_ulong),
+                ("dH", C.c_double), ("dK", C.c_double), ("dE", C.c_double), ("dprior", C.c_double),
+                ("dlikeli", C.c_double), ("psi_prior_i", C.c_double), ("psi_prior_f", C.c_double),
+                ("psi_likeli_i", C.c_double), ("psi_likeli_f", C.c_double), ("H_kin_i", C.c_double),
+                ("H_kin_f", C.c_double)]
+
+
 UNIFORM_FN = C.CFUNCTYPE(C.c_double, C.c_void_p)
 
 
@@ -77,10 +87,16 @@ def load():
     lib.bchmc_shim_delta_Hamiltonian.argtypes = [hv, _dp, _dp, _dp, _dp, _dp, C.c_char_p, sz]
     lib.bchmc_shim_gradient_psi.argtypes = [hv, _dp, C.c_char_p, sz]
     lib.bchmc_shim_measure_spectrum.argtypes = [hv, _dp, _dp, _dp, ul, C.c_char_p, sz]
+    lib.bchmc_shim_chain_set_state.argtypes = [hv, _dp, C.c_char_p, sz]
+    lib.bchmc_shim_chain_get_state.argtypes = [hv, _dp, C.c_char_p, sz]
+    lib.bchmc_shim_HamiltonianMC.argtypes = [hv, UNIFORM_FN, C.c_void_p, C.c_uint64, ul, C.POINTER(ul),
+                                             C.POINTER(AttemptLog), C.POINTER(ul), C.c_char_p, sz]
+    lib.bchmc_shim_sizeof_attempt_log.restype = sz
     lib.bchmc_shim_release.argtypes = [hv]
     lib.bchmc_shim_release.restype = None
     if lib.bchmc_shim_sizeof_view() != C.sizeof(HamilView) or \
-            lib.bchmc_shim_sizeof_numerical() != C.sizeof(HamilNumericalView):
+            lib.bchmc_shim_sizeof_numerical() != C.sizeof(HamilNumericalView) or \
+            lib.bchmc_shim_sizeof_attempt_log() != C.sizeof(AttemptLog):
         raise ImportError("bchmc_shim.hpp and barcode_amd/shim.py disagree on the struct layouts")
     _lib = lib
     return lib
@@ -165,6 +181,24 @@ class ShimHamil:
         self._chk(self.lib.bchmc_shim_measure_spectrum(C.byref(self.hd), _p(self._in(signal)), _p(km), _p(pw), N_bin,
                                                        self._err, len(self._err)))
         return km, pw
+
+    def chain_set_state(self, x):
+        self._chk(self.lib.bchmc_shim_chain_set_state(C.byref(self.hd), _p(self._in(x)), self._err, len(self._err)))
+
+    def chain_get_state(self):
+        x = np.empty(self.N)
+        self._chk(self.lib.bchmc_shim_chain_get_state(C.byref(self.hd), _p(x), self._err, len(self._err)))
+        return x
+
+    def HamiltonianMC(self, uniform, seed=1, itmax=2000):
+        """One sample of the C++ HamiltonianMC loop (device momentum draw).  Returns the list of attempt records."""
+        log = (AttemptLog * itmax)()
+        n = C.c_ulong(0)
+        cb = UNIFORM_FN(lambda _state: float(uniform()))
+        self._chk(self.lib.bchmc_shim_HamiltonianMC(C.byref(self.hd), cb, None, int(seed), int(itmax),
+                                                    C.byref(self.count_attempts), log, C.byref(n), self._err,
+                                                    len(self._err)))
+        return [{k: getattr(log[i], k) for k, _ in AttemptLog._fields_} for i in range(n.value)]
 
     def out(self, name):
         """hd->gradpsi / deltaX / posx / posy / posz as the C++ layer left them."""

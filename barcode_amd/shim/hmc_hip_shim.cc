@@ -2,6 +2,7 @@
 // Pure host C++11 (g++), no HIP: everything numerical happens in libbarcode_hip.so.
 #include "bchmc_shim.hpp"
 
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 
@@ -153,6 +154,80 @@ void measure_spectrum(HamilView *hd, const real_prec *signal, real_prec *kmode, 
   if (rc) fail(h, rc, "measure_spectrum");
 }
 
+void chain_set_state(HamilView *hd, const real_prec *x) {
+  bchmc_handle *h = engine_for(hd);
+  const int rc = bchmc_chain_set_state(h, x);
+  if (rc) fail(h, rc, "chain_set_state");
+}
+
+void chain_get_state(HamilView *hd, real_prec *x) {
+  bchmc_handle *h = engine_for(hd);
+  const int rc = bchmc_chain_get_state(h, x);
+  if (rc) fail(h, rc, "chain_get_state");
+}
+
+ULONG HamiltonianMC(HamilView *hd, uniform_fn uniform, void *rng_state, uint64_t seed, ULONG itmax, ULONG *count_attempts,
+                    AttemptLog *log, momenta_fn momenta, void *momenta_state) {
+  bchmc_handle *h = engine_for(hd);
+  HamilNumericalView *n = hd->numerical;
+  std::string host_p;
+  if (momenta) host_p.resize(n->N * sizeof(real_prec));
+  ULONG it = 0;
+  for (; it < itmax;) {
+    const ULONG attempt = count_attempts ? *count_attempts : it;
+    int rc;
+    if (momenta) {  // HMC.cc:445-447 with the caller's generator
+      real_prec *p = reinterpret_cast<real_prec *>(&host_p[0]);
+      momenta(momenta_state, p, n->N);
+      rc = bchmc_chain_set_momenta(h, p);
+    } else {
+      rc = bchmc_chain_draw_momenta(h, seed, attempt);
+    }
+    if (rc) fail(h, rc, "draw_momenta");
+    // HMC.cc:260-264
+    n->Neps = static_cast<ULONG>(n->N_eps_fac * uniform(rng_state)) + 1;
+    n->epsilon = static_cast<real_prec>(n->eps_fac * uniform(rng_state));
+    if (n->epsilon > 2.) n->epsilon = 2.;
+    double dH = 0., t[6];
+    uint64_t done = 0;
+    rc = bchmc_chain_attempt(h, n->epsilon, n->Neps, &dH, t, &done);
+    if (rc) fail(h, rc, "Hamiltonian_EoM");
+    if (count_attempts) ++*count_attempts;  // HMC.cc:368
+    n->H_kin_i = t[0]; n->psi_prior_i = t[1]; n->psi_likeli_i = t[2];
+    n->H_kin_f = t[3]; n->psi_prior_f = t[4]; n->psi_likeli_f = t[5];
+    n->psi_prior = t[4]; n->psi_likeli = t[5];
+    n->dprior = t[4] - t[1];
+    n->dlikeli = t[5] - t[2];
+    n->dK = t[3] - t[0];
+    n->dE = n->dprior + n->dlikeli;
+    n->dH = dH;
+    // HMC.cc:462-486
+    real_prec p_acceptance = 1.;
+    if (dH < 0.)
+      p_acceptance = 1.;
+    else if (std::exp(-dH) < 1.)
+      p_acceptance = std::exp(-dH);
+    bool accepted;
+    if (p_acceptance >= 1.)
+      accepted = true;
+    else
+      accepted = uniform(rng_state) < p_acceptance;
+    rc = bchmc_chain_accept(h, accepted ? 1 : 0);
+    if (rc) fail(h, rc, "chain_accept");
+    AttemptLog &r = log[it];
+    r.accepted = accepted;
+    r.epsilon = n->epsilon;
+    r.Neps = n->Neps;
+    r.steps_done = static_cast<ULONG>(done);
+    r.dH = dH; r.dK = n->dK; r.dE = n->dE; r.dprior = n->dprior; r.dlikeli = n->dlikeli;
+    r.psi_prior_i = t[1]; r.psi_prior_f = t[4]; r.psi_likeli_i = t[2]; r.psi_likeli_f = t[5];
+    r.H_kin_i = t[0]; r.H_kin_f = t[3];
+    ++it;
+    if (accepted) break;
+  }
+  return it;
+}
+
 void inputs_changed(HamilView *hd) {
   if (hd && hd->engine) upload_inputs(hd, static_cast<bchmc_handle *>(hd->engine));
 }
@@ -202,6 +277,20 @@ int bchmc_shim_measure_spectrum(bchmc_shim::HamilView *hd, const double *signal,
                                 unsigned long N_bin, char *err, size_t errlen) {
   return guarded(err, errlen, [&] { bchmc_shim::measure_spectrum(hd, signal, kmode, power, N_bin); });
 }
+int bchmc_shim_chain_set_state(bchmc_shim::HamilView *hd, const double *x, char *err, size_t errlen) {
+  return guarded(err, errlen, [&] { bchmc_shim::chain_set_state(hd, x); });
+}
+int bchmc_shim_chain_get_state(bchmc_shim::HamilView *hd, double *x, char *err, size_t errlen) {
+  return guarded(err, errlen, [&] { bchmc_shim::chain_get_state(hd, x); });
+}
+int bchmc_shim_HamiltonianMC(bchmc_shim::HamilView *hd, bchmc_shim::uniform_fn uniform, void *rng_state, uint64_t seed,
+                             unsigned long itmax, unsigned long *count_attempts, bchmc_shim::AttemptLog *log,
+                             unsigned long *n_attempts, char *err, size_t errlen) {
+  return guarded(err, errlen, [&] {
+    *n_attempts = bchmc_shim::HamiltonianMC(hd, uniform, rng_state, seed, itmax, count_attempts, log, nullptr, nullptr);
+  });
+}
+size_t bchmc_shim_sizeof_attempt_log(void) { return sizeof(bchmc_shim::AttemptLog); }
 void bchmc_shim_release(bchmc_shim::HamilView *hd) { bchmc_shim::release(hd); }
 size_t bchmc_shim_sizeof_view(void) { return sizeof(bchmc_shim::HamilView); }
 size_t bchmc_shim_sizeof_numerical(void) { return sizeof(bchmc_shim::HamilNumericalView); }

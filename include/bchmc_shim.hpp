@@ -81,6 +81,26 @@ real_prec kinetic_term(HamilView *hd, const real_prec *momenta);  // HMC.cc:64-1
 real_prec psi(HamilView *hd, const real_prec *signal);            // HMC.cc:124-143 (stores psi_prior, psi_likeli)
 // field_statistics.cpp:20-90
 void measure_spectrum(HamilView *hd, const real_prec *signal, real_prec *kmode, real_prec *power, ULONG N_bin);
+// ---- HamiltonianMC on the device-resident chain (HMC.cc:431-511) -------------------------------
+// The row of performance_log.txt (HMC.cc:40-60) of one attempt.
+struct AttemptLog {
+  bool accepted = false;
+  real_prec epsilon = 0;
+  ULONG Neps = 0, steps_done = 0;
+  real_prec dH = 0, dK = 0, dE = 0, dprior = 0, dlikeli = 0;
+  real_prec psi_prior_i = 0, psi_prior_f = 0, psi_likeli_i = 0, psi_likeli_f = 0, H_kin_i = 0, H_kin_f = 0;
+};
+// Host-side momentum draw (e.g. the caller's draw_momenta on its gsl_rng, HMC_momenta.cc:42-94): fills N doubles.
+using momenta_fn = void (*)(void *state, real_prec *momenta, ULONG N);
+void chain_set_state(HamilView *hd, const real_prec *x);  // hd->x -> HBM, once per sample
+void chain_get_state(HamilView *hd, real_prec *x);
+// One sample: repeat { momenta; (Neps, epsilon) from `uniform` in the reference's order (HMC.cc:260-261); trajectory;
+// dH; Metropolis test, statement for statement HMC.cc:462-486 (a uniform is consumed only when p_acceptance < 1) }
+// until accepted or `itmax` attempts.  Momenta: `momenta` if given, else the engine's counter-based device draw
+// (seed, attempt index).  Fills log[0 .. return value - 1]; *count_attempts advances like HMC.cc:368.
+ULONG HamiltonianMC(HamilView *hd, uniform_fn uniform, void *rng_state, uint64_t seed, ULONG itmax, ULONG *count_attempts,
+                    AttemptLog *log, momenta_fn momenta, void *momenta_state);
+
 // hd's input arrays changed (HamiltonianMC recomputes the mass every sample, HMC.cc:400-423): upload them again
 void inputs_changed(HamilView *hd);
 void release(HamilView *hd);
@@ -98,6 +118,12 @@ int bchmc_shim_delta_Hamiltonian(bchmc_shim::HamilView *hd, const double *signal
 int bchmc_shim_gradient_psi(bchmc_shim::HamilView *hd, const double *signal, char *err, size_t errlen);
 int bchmc_shim_measure_spectrum(bchmc_shim::HamilView *hd, const double *signal, double *kmode, double *power,
                                 unsigned long N_bin, char *err, size_t errlen);
+int bchmc_shim_chain_set_state(bchmc_shim::HamilView *hd, const double *x, char *err, size_t errlen);
+int bchmc_shim_chain_get_state(bchmc_shim::HamilView *hd, double *x, char *err, size_t errlen);
+int bchmc_shim_HamiltonianMC(bchmc_shim::HamilView *hd, bchmc_shim::uniform_fn uniform, void *rng_state, uint64_t seed,
+                             unsigned long itmax, unsigned long *count_attempts, bchmc_shim::AttemptLog *log,
+                             unsigned long *n_attempts, char *err, size_t errlen);
+size_t bchmc_shim_sizeof_attempt_log(void);
 void bchmc_shim_release(bchmc_shim::HamilView *hd);
 size_t bchmc_shim_sizeof_view(void);
 size_t bchmc_shim_sizeof_numerical(void);

@@ -56,3 +56,43 @@ def test_cpp_layer_throws_like_the_reference():
         hd2.gradient_psi(c.q0)
     hd.close()
     hd2.close()
+
+
+def test_cpp_hamiltonian_mc_loop_matches_the_python_mirror():
+    """bchmc_shim::HamiltonianMC (C++, HMC.cc:431-511 on the resident chain) consumes the uniform stream and takes the
+    accept/reject decisions exactly like barcode_amd.hamil.HamiltonianMC; same device momentum draw (seed, attempt)."""
+    from barcode_amd import hamil
+    from barcode_amd.shim import ShimHamil
+    c = Case(Nx=16, likelihood=1, rsd_model=1)
+    eps_fac = 12 * c.eps  # large steps: some attempts are rejected
+
+    def stream():
+        rng = np.random.default_rng(123)
+        return lambda: float(rng.random())
+
+    hd = ShimHamil(c.p, N_eps_fac=4.0, eps_fac=eps_fac, **c.arrays())
+    hd.chain_set_state(c.q0)
+    u = stream()
+    logs_cpp = [hd.HamiltonianMC(u, seed=5, itmax=30) for _ in range(3)]
+    x_cpp = hd.chain_get_state()
+    hd.close()
+
+    hp = hamil.HamilData(c.p, N_eps_fac=4.0, eps_fac=eps_fac, **c.arrays())
+    hp.engine.chain_set_state(c.q0)
+    u = stream()
+    logs_py = [hamil.HamiltonianMC(hp, u, seed=5, itmax=30) for _ in range(3)]
+    x_py = hp.engine.chain_get_state()
+    hp.engine.close()
+
+    assert [len(l) for l in logs_cpp] == [len(l) for l in logs_py]
+    for lc, lp in zip(logs_cpp, logs_py):
+        for a, b in zip(lc, lp):
+            assert a["accepted"] == b["accepted"] and a["Neps"] == b["Neps"] and a["steps_done"] == b["steps_done"]
+            assert np.isclose(a["epsilon"], b["epsilon"], rtol=1e-15)
+            # rejected attempts with these large steps are unstable trajectories (dH ~ 1e5): compare relative to the
+            # largest energy term involved
+            scale = max(abs(b[k]) for k in ("H_kin_i", "psi_prior_i", "psi_likeli_i", "H_kin_f", "psi_prior_f",
+                                             "psi_likeli_f", "dH"))
+            assert abs(a["dH"] - b["dH"]) <= 1e-8 * scale
+        assert lc[-1]["accepted"] or len(lc) == 30
+    assert rel_l2(x_cpp, x_py) < 1e-11
