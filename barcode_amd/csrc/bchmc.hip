@@ -1327,21 +1327,31 @@ int bchmc_create(const bchmc_config *cfg, bchmc_handle **out) {
         h->log2n = l2;
         const size_t len2[2] = {(size_t)g.n, (size_t)g.n};
         const size_t rs2[2] = {1, (size_t)g.n}, cs2[2] = {1, (size_t)g.nhp};
+        // optional fast path: if rocFFT refuses the 2-D strided plans, the batched 3-D plans carry every step
         rocfft_plan_description f2 = nullptr, i2 = nullptr;
-        FFTCHK(rocfft_plan_description_create(&f2));
-        FFTCHK(rocfft_plan_description_create(&i2));
-        FFTCHK(rocfft_plan_description_set_data_layout(f2, rocfft_array_type_real, rocfft_array_type_hermitian_interleaved,
-                                                       nullptr, nullptr, 2, rs2, (size_t)g.n * g.n, 2, cs2,
-                                                       (size_t)g.n * g.nhp));
-        FFTCHK(rocfft_plan_description_set_data_layout(i2, rocfft_array_type_hermitian_interleaved, rocfft_array_type_real,
-                                                       nullptr, nullptr, 2, cs2, (size_t)g.n * g.nhp, 2, rs2,
-                                                       (size_t)g.n * g.n));
-        FFTCHK(rocfft_plan_create(&h->r2c2d, rocfft_placement_notinplace, rocfft_transform_type_real_forward, prec, 2, len2,
-                                  3 * (size_t)g.n, f2));
-        FFTCHK(rocfft_plan_create(&h->c2r2d, rocfft_placement_notinplace, rocfft_transform_type_real_inverse, prec, 2, len2,
-                                  3 * (size_t)g.n, i2));
-        rocfft_plan_description_destroy(f2);
-        rocfft_plan_description_destroy(i2);
+        bool ok2 = rocfft_plan_description_create(&f2) == rocfft_status_success &&
+                   rocfft_plan_description_create(&i2) == rocfft_status_success;
+        ok2 = ok2 && rocfft_plan_description_set_data_layout(f2, rocfft_array_type_real,
+                                                             rocfft_array_type_hermitian_interleaved, nullptr, nullptr, 2,
+                                                             rs2, (size_t)g.n * g.n, 2, cs2,
+                                                             (size_t)g.n * g.nhp) == rocfft_status_success;
+        ok2 = ok2 && rocfft_plan_description_set_data_layout(i2, rocfft_array_type_hermitian_interleaved,
+                                                             rocfft_array_type_real, nullptr, nullptr, 2, cs2,
+                                                             (size_t)g.n * g.nhp, 2, rs2,
+                                                             (size_t)g.n * g.n) == rocfft_status_success;
+        ok2 = ok2 && rocfft_plan_create(&h->r2c2d, rocfft_placement_notinplace, rocfft_transform_type_real_forward, prec,
+                                        2, len2, 3 * (size_t)g.n, f2) == rocfft_status_success;
+        ok2 = ok2 && rocfft_plan_create(&h->c2r2d, rocfft_placement_notinplace, rocfft_transform_type_real_inverse, prec,
+                                        2, len2, 3 * (size_t)g.n, i2) == rocfft_status_success;
+        if (f2) rocfft_plan_description_destroy(f2);
+        if (i2) rocfft_plan_description_destroy(i2);
+        if (!ok2) {
+          for (rocfft_plan *pp : {&h->r2c2d, &h->c2r2d})
+            if (*pp) {
+              rocfft_plan_destroy(*pp);
+              *pp = nullptr;
+            }
+        }
         // twiddles exp(-2 pi i r / n), r < n / 2, from the host's libm
         std::vector<double> tw(g.n);
         for (int r = 0; r < g.n / 2; r++) {
@@ -1358,7 +1368,7 @@ int bchmc_create(const bchmc_config *cfg, bchmc_handle **out) {
           HIPCHK(hipMemcpyAsync(h->xtw, tw.data(), tw.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
           HIPCHK(hipStreamSynchronize(h->stream));
         }
-        h->planes_ok = true;
+        h->planes_ok = ok2;
       }
     }
     for (rocfft_plan p : {h->r2c1, h->c2r1, h->r2c3, h->c2r3, h->r2c2d, h->c2r2d}) {
