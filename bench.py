@@ -10,6 +10,11 @@ half kick).  The timed region is ONE trajectory of exactly K steps through the C
 input grids already resident in HBM, bracketed by barrier + torch.cuda.synchronize().  Each rank runs its own
 independent chain (weak scaling); the only collective is the 16-byte/rank epsilon-statistics all-gather
 per trajectory (RCCL).  Rank 0 prints one JSON line.
+
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment launches its own N ranks: the parent
+process starts N children (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set) before it
+touches the GPU -- it never does -- waits for them, relays rank 0's JSON line and propagates a non-zero exit code.
+Under torch.distributed.run the ranks exist already; --gpus must then equal WORLD_SIZE.
 """
 import argparse
 import json
@@ -62,27 +67,111 @@ def pmc_traffic(nx, precision):
     return best[1]["hbm_bytes_per_step"], os.path.relpath(best[0], ROOT)
 
 
-def cpu_baseline(params, case_arrays, q0, p0, eps):
-    """Oracle (kind "port", OpenMP build) timed on this box's host cores on a bounded sample of the same
-    workload: per-step time = (t(trajectory of 3 steps) - t(trajectory of 1 step)) / 2."""
+def _rel_l2(a, b):
+    import numpy as np
+    a, b = np.asarray(a).ravel(), np.asarray(b).ravel()
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+def cpu_baseline(params, case_arrays, q0, p0, eps, reps=3):
+    """Oracle (kind "port") timed on this box's host cores on a bounded sample of the same workload
+    (SURVEY 8d protocol): OpenMP build on all host cores, `reps` repetitions, per-step time of a repetition =
+    (t[3-step trajectory] - t[1-step trajectory]) / 2 (the initial force evaluation and the state copies cancel),
+    median reported; plus a 1-core figure from the serial build on a 64^3 sample of the same recipe.
+    Returns (json object, (q1, p1) of the oracle's 3-step trajectory for the parity-at-size check)."""
+    import numpy as np
     from oracle.oracle import Oracle
     cores = int(os.environ.get("OMP_NUM_THREADS", "1"))
     o = Oracle(params, omp=True)
     o.set(**case_arrays)
-    t0 = time.perf_counter()
-    o.Hamiltonian_EoM(q0, p0, eps, 1)
-    t1 = time.perf_counter()
-    o.Hamiltonian_EoM(q0, p0, eps, 3)
-    t2 = time.perf_counter()
+    per_step, total, traj3 = [], 0.0, None
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        o.Hamiltonian_EoM(q0, p0, eps, 1)
+        t1 = time.perf_counter()
+        q1, p1, _done = o.Hamiltonian_EoM(q0, p0, eps, 3)
+        t2 = time.perf_counter()
+        per_step.append(((t2 - t1) - (t1 - t0)) / 2.0)
+        total += t2 - t0
+        if traj3 is None:
+            traj3 = (np.array(q1, copy=True), np.array(p1, copy=True))
     o.close()
-    per_step = ((t2 - t1) - (t1 - t0)) / 2.0
-    return dict(value=1.0 / per_step, unit="steps/s", cores=cores, kind="port",
-                sample="oracle/liboracle_omp.so, %d^3 grid, same inputs: (t[3-step trajectory] - t[1-step trajectory])/2 "
-                       "= %.2f s per leapfrog step; %.1f s of CPU work in total" % (params.Nx, per_step, t2 - t0))
+    med = float(np.median(per_step))
+    # 1 core: the serial build (same source, gcc -O2) on a 64^3 grid of the same recipe, 3 repetitions
+    from tests.util import Case
+    c1 = Case(Nx=64, L=params.L * 64.0 / params.Nx, likelihood=params.likelihood, rsd_model=params.rsd_model,
+              sfmodel=params.sfmodel)
+    one = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        c1.oracle.Hamiltonian_EoM(c1.q0, c1.p0, c1.eps, 1)
+        t1 = time.perf_counter()
+        c1.oracle.Hamiltonian_EoM(c1.q0, c1.p0, c1.eps, 3)
+        t2 = time.perf_counter()
+        one.append(((t2 - t1) - (t1 - t0)) / 2.0)
+        total += t2 - t0
+    c1.oracle.close()
+    one_med = float(np.median(one))
+    return dict(value=1.0 / med, unit="steps/s", cores=cores, kind="port", repetitions=reps,
+                per_step_s=[round(x, 3) for x in per_step],
+                cell_steps_per_s=params.N / med,
+                one_core=dict(value=1.0 / one_med, unit="steps/s", grid=64, cores=1,
+                              cell_steps_per_s=64 ** 3 / one_med, per_step_s=[round(x, 4) for x in one],
+                              build="oracle/liboracle.so (serial, gcc -O2)"),
+                fft_backend="oracle/orc_fft.c (bundled radix-2/4 + Bluestein row FFTs, OpenMP over rows; no FFTW3 on "
+                            "this image)",
+                sample="oracle/liboracle_omp.so (gcc -O3 -march=x86-64-v3 -fopenmp, %d threads), %d^3 grid, same "
+                       "inputs as the GPU run: median over %d repetitions of (t[3-step trajectory] - t[1-step "
+                       "trajectory])/2 = %.2f s per leapfrog step; 1-core figure: serial build, 64^3 grid of the same "
+                       "recipe, %.3f s per step; %.0f s of CPU work in total" % (cores, params.Nx, reps, med, one_med,
+                                                                               total)), traj3
+
+
+def valu_roofline():
+    """fp64 vector-ALU roofline of the two particle-mesh kernels from the newest committed SQ-counter summary
+    (profiles/r*_sq_tile81.json, made by scripts/pmc_sq.py from separate rocprofv3 --pmc passes of this bench
+    command; PMC needs its own passes, so this is never measured inside the timed run)."""
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sq_tile81.json")))
+    if not paths:
+        return None
+    try:
+        d = json.load(open(paths[-1]))
+    except (OSError, ValueError):
+        return None
+    d["source"] = os.path.relpath(paths[-1], ROOT)
+    d["measured_in_run"] = False
+    return d
+
+
+def launch_ranks(args):
+    """Parent of a self-launched multi-GPU run: start one child per GPU, never touch the GPU here."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                   BCHMC_BENCH_CHILD="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    bad = [rc for rc in rcs if rc]
+    if bad:
+        print("bench.py: rank exit codes %s" % rcs, file=sys.stderr)
+        sys.exit(bad[0] if bad[0] > 0 else 1)
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args)  # parent: no torch.cuda / engine call has happened or will happen here
     # host threads for the CPU baseline (must be set before the OpenMP library loads)
     try:
         ncores = len(os.sched_getaffinity(0))
@@ -101,8 +190,13 @@ def main():
     distributed = world > 1
     if distributed:
         dist.init_process_group(args.backend, rank=rank, world_size=world)
-    if args.gpus != world and rank == 0:
-        print("bench.py: --gpus %d but WORLD_SIZE %d; running %d rank(s)" % (args.gpus, world, world), file=sys.stderr)
+    if args.gpus != world:
+        # a wrong rank count must never be recorded as an N-GPU number
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE %d: refusing to run" % (args.gpus, world), file=sys.stderr)
+        if distributed:
+            dist.destroy_process_group()
+        sys.exit(2)
     if args.single_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -237,10 +331,13 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": traffic,
                 "traffic_source": traffic_src,
+                "traffic_measured_in_run": False,  # PMC needs its own rocprofv3 passes (scripts/profile_round.sh)
                 "algorithmic_bytes_per_step": algo * N,
                 "device_ms_per_step": round(gpu_ms / args.steps, 4),
                 "dominant_kernel": dominant,
                 "kernels": kernels,
+                # the two particle-mesh kernels are fp64-VALU bound, not HBM bound: reported against 78.6 TFLOP/s
+                "valu": valu_roofline() if (rsd and params.likelihood == 1 and not args.fp32 and params.Nx == 256) else None,
             },
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -251,7 +348,18 @@ def main():
                 c = Case(Nx=args.cpu_nx, L=200.0 * args.cpu_nx / params.Nx, likelihood=params.likelihood,
                          rsd_model=rsd)
                 cpu_params, cq0, cp0, carr = c.p, c.q0, c.p0, c.arrays()
-            out["cpu_baseline"] = cpu_baseline(cpu_params, carr, cq0, cp0, eps)
+            out["cpu_baseline"], (q3o, p3o) = cpu_baseline(cpu_params, carr, cq0, cp0, eps)
+            # parity at the benchmarked size: the oracle's 3-step trajectory (just timed) against a 3-step engine
+            # trajectory on the same inputs, through the same entry point and kernel instantiations the bench times
+            if cpu_params is params:
+                e3q, e3p = torch.empty_like(q0), torch.empty_like(p0)
+                engine.leapfrog_device(q0, p0, e3q, e3p, eps, 3)
+                engine.sync()
+                tol = 1e-4 if args.fp32 else 1e-11
+                rq, rp = _rel_l2(e3q.cpu().numpy(), q3o), _rel_l2(e3p.cpu().numpy(), p3o)
+                out["parity_at_size"] = dict(grid=params.Nx, steps=3, rel_l2_q=rq, rel_l2_p=rp, tolerance=tol,
+                                             ok=bool(rq < tol and rp < tol),
+                                             oracle="oracle/liboracle_omp.so (parity unpinned: no reference vectors exist)")
         print(json.dumps(out))
     if distributed:
         dist.barrier()
