@@ -57,10 +57,22 @@ def gaussian_random_field(params, spectrum, seed, scale=1.0):
     """Real field f with <|FFT f|^2> = N^2 * spectrum / V, Hermitian by construction."""
     n, N, V = params.Nx, params.N, params.L ** 3
     white = _rng(seed).standard_normal((n, n, n))
-    wk = np.fft.rfftn(white)
     amp = np.sqrt(np.maximum(spectrum[:, :, : n // 2 + 1], 0.0) * (N / V))
-    f = np.fft.irfftn(wk * amp, s=(n, n, n), axes=(0, 1, 2))
-    return np.ascontiguousarray(scale * f)
+    if n >= 256:
+        # BASELINE-size grids: threaded pocketfft (same algorithm; last-bit differences from numpy's serial one do
+        # not matter, every consumer of a case reads the same arrays).  Small grids keep numpy: the golden fixtures
+        # were generated with it.
+        from scipy import fft as sfft
+        wk = sfft.rfftn(white, workers=-1)
+        del white
+        wk *= amp
+        f = sfft.irfftn(wk, s=(n, n, n), axes=(0, 1, 2), workers=-1, overwrite_x=True)
+    else:
+        wk = np.fft.rfftn(white)
+        f = np.fft.irfftn(wk * amp, s=(n, n, n), axes=(0, 1, 2))
+    if scale != 1.0:
+        f *= scale
+    return np.ascontiguousarray(f)
 
 
 def mock_observations(params, delta_eul, seed=SEED_NOBS, delta_lag=None, sigma_fac_lognormal=0.1):

@@ -2,9 +2,14 @@
 // Pure host C++11 (g++), no HIP: everything numerical happens in libbarcode_hip.so.
 #include "bchmc_shim.hpp"
 
+#include <unistd.h>
+
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <thread>
+#include <vector>
 
 namespace bchmc_shim {
 namespace {
@@ -30,7 +35,14 @@ void upload_inputs(HamilView *hd, bchmc_handle *h) {
 
 bchmc_handle *engine_for(HamilView *hd) {
   if (!hd || !hd->numerical) throw std::runtime_error("In hmc_hip_shim: HAMIL_DATA without numerical");
-  if (hd->engine) return static_cast<bchmc_handle *>(hd->engine);
+  if (hd->engine) {
+    bchmc_handle *h = static_cast<bchmc_handle *>(hd->engine);
+    if (hd->uploaded_generation != hd->inputs_generation) {  // inputs_changed() since the last upload
+      upload_inputs(hd, h);
+      hd->uploaded_generation = hd->inputs_generation;
+    }
+    return h;
+  }
   const HamilNumericalView *n = hd->numerical;
   bchmc_config c;
   std::memset(&c, 0, sizeof c);
@@ -64,6 +76,7 @@ bchmc_handle *engine_for(HamilView *hd) {
   }
   hd->engine = h;
   upload_inputs(hd, h);
+  hd->uploaded_generation = hd->inputs_generation;
   return h;
 }
 
@@ -128,24 +141,21 @@ void gradient_psi(HamilView *hd, const real_prec *signal) {
 
 real_prec kinetic_term(HamilView *hd, const real_prec *momenta) {
   bchmc_handle *h = engine_for(hd);
-  // bchmc_energies evaluates the three terms together; the kinetic one does not depend on the signal
-  std::string zeros(hd->numerical->N * sizeof(real_prec), '\0');
-  double e[3];
-  const int rc = bchmc_energies(h, reinterpret_cast<const real_prec *>(zeros.data()), momenta, e);
+  double k = 0.;
+  const int rc = bchmc_kinetic_term(h, momenta, &k);  // one R2C + one Parseval sum; needs mass_f / mass_r only
   if (rc) fail(h, rc, "kinetic_term");
-  return e[0];
+  return k;
 }
 
 real_prec psi(HamilView *hd, const real_prec *signal) {
   bchmc_handle *h = engine_for(hd);
-  std::string zeros(hd->numerical->N * sizeof(real_prec), '\0');
-  double e[3];
-  const int rc = bchmc_energies(h, signal, reinterpret_cast<const real_prec *>(zeros.data()), e);
+  double e[2];
+  const int rc = bchmc_psi(h, signal, e);
   if (rc) fail(h, rc, "psi");
-  hd->numerical->psi_prior = e[1];  // HMC.cc:139-140
-  hd->numerical->psi_likeli = e[2];
+  hd->numerical->psi_prior = e[0];  // HMC.cc:139-140
+  hd->numerical->psi_likeli = e[1];
   fetch_eval_state(hd, h);
-  return e[1] + e[2];
+  return e[0] + e[1];
 }
 
 void measure_spectrum(HamilView *hd, const real_prec *signal, real_prec *kmode, real_prec *power, ULONG N_bin) {
@@ -166,32 +176,58 @@ void chain_get_state(HamilView *hd, real_prec *x) {
   if (rc) fail(h, rc, "chain_get_state");
 }
 
+namespace {
+int op_draw(void *e, uint64_t seed, uint64_t attempt) { return bchmc_chain_draw_momenta(static_cast<bchmc_handle *>(e), seed, attempt); }
+int op_setp(void *e, const real_prec *p) { return bchmc_chain_set_momenta(static_cast<bchmc_handle *>(e), p); }
+int op_attempt(void *e, double eps, uint64_t neps, double *dH, double terms[6], uint64_t *done) {
+  return bchmc_chain_attempt(static_cast<bchmc_handle *>(e), eps, neps, dH, terms, done);
+}
+int op_accept(void *e, int a) { return bchmc_chain_accept(static_cast<bchmc_handle *>(e), a); }
+}  // namespace
+
 ULONG HamiltonianMC(HamilView *hd, uniform_fn uniform, void *rng_state, uint64_t seed, ULONG itmax, ULONG *count_attempts,
-                    AttemptLog *log, momenta_fn momenta, void *momenta_state) {
+                    AttemptLog *log, ULONG log_cap, momenta_fn momenta, void *momenta_state) {
   bchmc_handle *h = engine_for(hd);
+  const ChainOps ops = {op_draw, op_setp, op_attempt, op_accept};
+  try {
+    return HamiltonianMC_ops(hd, ops, h, uniform, rng_state, seed, itmax, count_attempts, log, log_cap, momenta,
+                             momenta_state);
+  } catch (const std::runtime_error &e) {
+    const char *detail = bchmc_last_error(h);
+    if (detail && detail[0]) throw std::runtime_error(std::string(e.what()) + " (" + detail + ")");
+    throw;
+  }
+}
+
+ULONG HamiltonianMC_ops(HamilView *hd, const ChainOps &ops, void *engine, uniform_fn uniform, void *rng_state,
+                        uint64_t seed, ULONG itmax, ULONG *count_attempts, AttemptLog *log, ULONG log_cap,
+                        momenta_fn momenta, void *momenta_state) {
+  if (!hd || !hd->numerical) throw std::runtime_error("In HamiltonianMC: HAMIL_DATA without numerical");
   HamilNumericalView *n = hd->numerical;
+  auto chk = [](int rc, const char *where) {
+    if (rc) throw std::runtime_error(std::string("In ") + where + ": " + bchmc_strerror(rc));
+  };
   std::string host_p;
   if (momenta) host_p.resize(n->N * sizeof(real_prec));
+  std::vector<bchmc_eps_record> mine;  // this sample's records, exchanged once after the loop
   ULONG it = 0;
-  for (; it < itmax;) {
+  while (it < itmax) {  // HMC.cc:431
     const ULONG attempt = count_attempts ? *count_attempts : it;
-    int rc;
-    if (momenta) {  // HMC.cc:445-447 with the caller's generator
+    if (momenta) {  // HMC.cc:445-449 with the caller's generator
       real_prec *p = reinterpret_cast<real_prec *>(&host_p[0]);
       momenta(momenta_state, p, n->N);
-      rc = bchmc_chain_set_momenta(h, p);
+      chk(ops.set_momenta(engine, p), "draw_momenta");
     } else {
-      rc = bchmc_chain_draw_momenta(h, seed, attempt);
+      chk(ops.draw_momenta(engine, seed, attempt), "draw_momenta");
     }
-    if (rc) fail(h, rc, "draw_momenta");
+    update_eps_fac(hd);  // HMC.cc:453
     // HMC.cc:260-264
     n->Neps = static_cast<ULONG>(n->N_eps_fac * uniform(rng_state)) + 1;
     n->epsilon = static_cast<real_prec>(n->eps_fac * uniform(rng_state));
     if (n->epsilon > 2.) n->epsilon = 2.;
-    double dH = 0., t[6];
+    double dH = 0., t[6] = {0., 0., 0., 0., 0., 0.};
     uint64_t done = 0;
-    rc = bchmc_chain_attempt(h, n->epsilon, n->Neps, &dH, t, &done);
-    if (rc) fail(h, rc, "Hamiltonian_EoM");
+    chk(ops.attempt(engine, n->epsilon, n->Neps, &dH, t, &done), "Hamiltonian_EoM");
     if (count_attempts) ++*count_attempts;  // HMC.cc:368
     n->H_kin_i = t[0]; n->psi_prior_i = t[1]; n->psi_likeli_i = t[2];
     n->H_kin_f = t[3]; n->psi_prior_f = t[4]; n->psi_likeli_f = t[5];
@@ -212,24 +248,95 @@ ULONG HamiltonianMC(HamilView *hd, uniform_fn uniform, void *rng_state, uint64_t
       accepted = true;
     else
       accepted = uniform(rng_state) < p_acceptance;
-    rc = bchmc_chain_accept(h, accepted ? 1 : 0);
-    if (rc) fail(h, rc, "chain_accept");
-    AttemptLog &r = log[it];
-    r.accepted = accepted;
-    r.epsilon = n->epsilon;
-    r.Neps = n->Neps;
-    r.steps_done = static_cast<ULONG>(done);
-    r.dH = dH; r.dK = n->dK; r.dE = n->dE; r.dprior = n->dprior; r.dlikeli = n->dlikeli;
-    r.psi_prior_i = t[1]; r.psi_prior_f = t[4]; r.psi_likeli_i = t[2]; r.psi_likeli_f = t[5];
-    r.H_kin_i = t[0]; r.H_kin_f = t[3];
+    chk(ops.accept(engine, accepted ? 1 : 0), "chain_accept");  // HMC.cc:497-498
+    if (!accepted) n->rejections++;                              // HMC.cc:500-501
+    n->accepted = accepted;                                      // HMC.cc:503-504
+    if (log && it < log_cap) {                                   // write_to_performance_log's row, HMC.cc:506
+      AttemptLog &r = log[it];
+      r.accepted = accepted;
+      r.epsilon = n->epsilon;
+      r.Neps = n->Neps;
+      r.steps_done = static_cast<ULONG>(done);
+      r.dH = dH; r.dK = n->dK; r.dE = n->dE; r.dprior = n->dprior; r.dlikeli = n->dlikeli;
+      r.psi_prior_i = t[1]; r.psi_prior_f = t[4]; r.psi_likeli_i = t[2]; r.psi_likeli_f = t[5];
+      r.H_kin_i = t[0]; r.H_kin_f = t[3];
+    }
+    update_epsilon_acc_rate_tables(hd);  // HMC.cc:507
+    if (hd->comm) {
+      bchmc_eps_record rec;
+      rec.epsilon = n->epsilon;
+      rec.accepted = accepted ? 1 : 0;
+      rec.neps = static_cast<int32_t>(n->Neps);
+      mine.push_back(rec);
+    }
     ++it;
     if (accepted) break;
+  }
+  if (hd->comm) {
+    // the fixed point every chain reaches once per sample: pool the step-size statistics
+    const int cap = 64 * BCHMC_EPS_BATCH;
+    std::vector<bchmc_eps_record> all(static_cast<size_t>(cap));
+    std::vector<int> rank_of(static_cast<size_t>(cap));
+    int n_all = 0;
+    // a communicator of more than 64 ranks would need a larger buffer; one node has 8
+    const int rc = bchmc_eps_exchange(hd->comm, mine.data(), static_cast<int>(mine.size()), all.data(), rank_of.data(),
+                                      cap, &n_all);
+    if (rc) throw std::runtime_error(std::string("In bchmc_eps_exchange: ") + bchmc_comm_last_error(hd->comm));
+    if (hd->eps)
+      for (int i = 0; i < n_all; i++)
+        if (rank_of[static_cast<size_t>(i)] != hd->comm_rank)  // own attempts are in the tables already
+          eps_adapt_append(hd->eps, all[static_cast<size_t>(i)].accepted != 0, all[static_cast<size_t>(i)].epsilon);
   }
   return it;
 }
 
+void comm_bootstrap_file(HamilView *hd, const char *path, int rank, int world, double timeout_s) {
+  if (!hd || !path) throw std::runtime_error("In comm_bootstrap_file: bad argument");
+  unsigned char id[BCHMC_UNIQUE_ID_BYTES];
+  const std::string final_path(path), tmp_path = final_path + ".tmp";
+  if (rank == 0) {
+    const int rc = bchmc_comm_unique_id(id);
+    if (rc) throw std::runtime_error(std::string("In bchmc_comm_unique_id: ") + bchmc_strerror(rc));
+    FILE *f = std::fopen(tmp_path.c_str(), "wb");
+    if (!f || std::fwrite(id, 1, sizeof id, f) != sizeof id || std::fclose(f) != 0)
+      throw std::runtime_error("In comm_bootstrap_file: cannot write " + tmp_path);
+    if (std::rename(tmp_path.c_str(), final_path.c_str()) != 0)  // atomic: readers never see a partial id
+      throw std::runtime_error("In comm_bootstrap_file: cannot rename to " + final_path);
+  } else {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+      FILE *f = std::fopen(final_path.c_str(), "rb");
+      if (f) {
+        const size_t got = std::fread(id, 1, sizeof id, f);
+        std::fclose(f);
+        if (got == sizeof id) break;
+      }
+      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s)
+        throw std::runtime_error("In comm_bootstrap_file: timed out waiting for " + final_path);
+      std::this_thread::sleep_for(std::chrono::milliseconds(20));
+    }
+  }
+  bchmc_comm *c = nullptr;
+  const int rc = bchmc_comm_create(id, rank, world, hd->device, &c);
+  if (rc) {
+    std::string msg = std::string("In bchmc_comm_create: ") + bchmc_strerror(rc);
+    if (c && bchmc_comm_last_error(c)[0]) msg += std::string(" (") + bchmc_comm_last_error(c) + ")";
+    if (c) bchmc_comm_destroy(c);
+    throw std::runtime_error(msg);
+  }
+  hd->comm = c;
+  hd->comm_rank = rank;
+}
+
+void comm_release(HamilView *hd) {
+  if (hd && hd->comm) {
+    bchmc_comm_destroy(hd->comm);
+    hd->comm = nullptr;
+  }
+}
+
 void inputs_changed(HamilView *hd) {
-  if (hd && hd->engine) upload_inputs(hd, static_cast<bchmc_handle *>(hd->engine));
+  if (hd) hd->inputs_generation++;  // the next engine_for() uploads the arrays again (once, not per call)
 }
 
 void release(HamilView *hd) {
@@ -285,11 +392,93 @@ int bchmc_shim_chain_get_state(bchmc_shim::HamilView *hd, double *x, char *err, 
 }
 int bchmc_shim_HamiltonianMC(bchmc_shim::HamilView *hd, bchmc_shim::uniform_fn uniform, void *rng_state, uint64_t seed,
                              unsigned long itmax, unsigned long *count_attempts, bchmc_shim::AttemptLog *log,
-                             unsigned long *n_attempts, char *err, size_t errlen) {
+                             unsigned long log_cap, unsigned long *n_attempts, char *err, size_t errlen) {
   return guarded(err, errlen, [&] {
-    *n_attempts = bchmc_shim::HamiltonianMC(hd, uniform, rng_state, seed, itmax, count_attempts, log, nullptr, nullptr);
+    *n_attempts = bchmc_shim::HamiltonianMC(hd, uniform, rng_state, seed, itmax, count_attempts, log, log_cap, nullptr,
+                                            nullptr);
   });
 }
+
+namespace {
+// scripted engine for the CPU tests of the loop's bookkeeping: attempt k returns dH = dH[k], no device involved
+struct Script {
+  const double *dH;
+  unsigned long n, k;
+};
+int sc_draw(void *, uint64_t, uint64_t) { return 0; }
+int sc_setp(void *, const double *) { return 0; }
+int sc_attempt(void *e, double, uint64_t neps, double *dH, double terms[6], uint64_t *done) {
+  Script *s = static_cast<Script *>(e);
+  if (s->k >= s->n) return BCHMC_ERR_STATE;
+  *dH = s->dH[s->k++];
+  for (int i = 0; i < 6; i++) terms[i] = 0.;
+  terms[3] = *dH;  // the whole difference in the kinetic term
+  if (done) *done = neps;
+  return 0;
+}
+int sc_accept(void *, int) { return 0; }
+}  // namespace
+
+int bchmc_shim_HamiltonianMC_scripted(bchmc_shim::HamilView *hd, const double *script_dH, unsigned long n_script,
+                                      bchmc_shim::uniform_fn uniform, void *rng_state, unsigned long itmax,
+                                      unsigned long *count_attempts, bchmc_shim::AttemptLog *log, unsigned long log_cap,
+                                      unsigned long *n_attempts, char *err, size_t errlen) {
+  return guarded(err, errlen, [&] {
+    Script sc = {script_dH, n_script, 0};
+    const bchmc_shim::ChainOps ops = {sc_draw, sc_setp, sc_attempt, sc_accept};
+    *n_attempts = bchmc_shim::HamiltonianMC_ops(hd, ops, &sc, uniform, rng_state, 0, itmax, count_attempts, log, log_cap,
+                                                nullptr, nullptr);
+  });
+}
+int bchmc_shim_kinetic_term(bchmc_shim::HamilView *hd, const double *momenta, double *out, char *err, size_t errlen) {
+  return guarded(err, errlen, [&] { *out = bchmc_shim::kinetic_term(hd, momenta); });
+}
+int bchmc_shim_psi(bchmc_shim::HamilView *hd, const double *signal, double *out, char *err, size_t errlen) {
+  return guarded(err, errlen, [&] { *out = bchmc_shim::psi(hd, signal); });
+}
+bchmc_shim::EpsAdapt *bchmc_shim_eps_create(int update_type, unsigned N_a, double acc_min, double acc_max, int down_smooth,
+                                            double up_fac, double target, double power, unsigned long s_eps_total) {
+  bchmc_shim::EpsAdaptConfig c;
+  c.eps_fac_update_type = update_type;
+  c.N_a_eps_update = N_a;
+  c.acc_min = acc_min;
+  c.acc_max = acc_max;
+  c.eps_down_smooth = down_smooth;
+  c.eps_up_fac = up_fac;
+  c.eps_fac_target = target;
+  c.eps_fac_power = power;
+  c.s_eps_total = s_eps_total;
+  try {
+    return bchmc_shim::eps_adapt_create(c);
+  } catch (const std::runtime_error &) {
+    return nullptr;
+  }
+}
+void bchmc_shim_eps_destroy(bchmc_shim::EpsAdapt *e) { bchmc_shim::eps_adapt_destroy(e); }
+void bchmc_shim_eps_append(bchmc_shim::EpsAdapt *e, int accepted, double epsilon) {
+  bchmc_shim::eps_adapt_append(e, accepted != 0, epsilon);
+}
+unsigned long bchmc_shim_eps_records(const bchmc_shim::EpsAdapt *e) { return bchmc_shim::eps_adapt_records(e); }
+double bchmc_shim_eps_acceptance_rate(const bchmc_shim::EpsAdapt *e) { return bchmc_shim::eps_adapt_acceptance_rate(e); }
+int bchmc_shim_update_eps_fac(bchmc_shim::HamilView *hd, char *msg, size_t msglen, char *err, size_t errlen) {
+  return guarded(err, errlen, [&] {
+    const std::string m = bchmc_shim::update_eps_fac(hd);
+    if (msg && msglen) std::snprintf(msg, msglen, "%s", m.c_str());
+  });
+}
+int bchmc_shim_update_tables(bchmc_shim::HamilView *hd, char *err, size_t errlen) {
+  return guarded(err, errlen, [&] { bchmc_shim::update_epsilon_acc_rate_tables(hd); });
+}
+int bchmc_shim_comm_bootstrap_file(bchmc_shim::HamilView *hd, const char *path, int rank, int world, double timeout_s,
+                                   char *err, size_t errlen) {
+  return guarded(err, errlen, [&] { bchmc_shim::comm_bootstrap_file(hd, path, rank, world, timeout_s); });
+}
+int bchmc_shim_comm_attach(bchmc_shim::HamilView *hd, bchmc_comm *comm) {
+  if (!hd) return 1;
+  hd->comm = comm;
+  return 0;
+}
+void bchmc_shim_inputs_changed(bchmc_shim::HamilView *hd) { bchmc_shim::inputs_changed(hd); }
 size_t bchmc_shim_sizeof_attempt_log(void) { return sizeof(bchmc_shim::AttemptLog); }
 void bchmc_shim_release(bchmc_shim::HamilView *hd) { bchmc_shim::release(hd); }
 size_t bchmc_shim_sizeof_view(void) { return sizeof(bchmc_shim::HamilView); }

@@ -115,6 +115,12 @@ int bchmc_leapfrog(bchmc_handle *h, const double *q0, const double *p0, double *
  * deltaX / pos* of this evaluation in the handle like the reference's log_like does. */
 int bchmc_energies(bchmc_handle *h, const double *q, const double *p, double out[3]);
 
+/* kinetic_term (HMC.cc:64-121) and psi (HMC.cc:124-143) on their own: one transform and one reduction for the
+ * kinetic term (needs mass_f / mass_r only); psi_out = { log_prior, log_like } with the forward model of `q` left in
+ * the handle (deltaX / pos*), like the reference's log_like leaves it in HAMIL_DATA. */
+int bchmc_kinetic_term(bchmc_handle *h, const double *p, double *out);
+int bchmc_psi(bchmc_handle *h, const double *q, double psi_out[2]);
+
 /* delta_Hamiltonian (HMC.cc:209-248): terms = { H_kin_i, psi_prior_i, psi_likeli_i, H_kin_f,
  * psi_prior_f, psi_likeli_f }, *dH includes div_dH_by_N. */
 int bchmc_delta_hamiltonian(bchmc_handle *h, const double *qi, const double *pi, const double *qf, const double *pf,
@@ -168,12 +174,47 @@ int bchmc_profile(bchmc_handle *h, int enable);                 /* 1: record eve
 int bchmc_profile_read(bchmc_handle *h, double ms[BCHMC_K_COUNT], uint64_t launches[BCHMC_K_COUNT]); /* and reset */
 const char *bchmc_kernel_name(int kernel_class);
 
-/* Cross-chain step-size statistics record: what each rank contributes per trajectory. */
+/* ---- cross-chain step-size statistics -------------------------------------------------------
+ * Chains are independent (one per GPU); the only exchange on the path is this record, one per finished attempt,
+ * so that every chain's acceptance / epsilon tables (acc_flag_N_a, epsilon_N_a: struct_main.h:172-173, written by
+ * update_epsilon_acc_rate_tables, time_step.cpp:187-203, read by update_eps_fac, :151-185) fill world_size times
+ * faster.  A chain that never calls bchmc_eps_exchange behaves exactly like the single-chain reference. */
 typedef struct bchmc_eps_record {
   double epsilon;
   int32_t accepted;
   int32_t neps;
 } bchmc_eps_record;
+
+/* Records one rank contributes per exchange.  The exchange happens ONCE PER SAMPLE (a fixed point every rank
+ * reaches the same number of times), never per attempt: the attempt loop ends at a data-dependent iteration, so a
+ * per-attempt collective would pair up records of different samples and deadlock the rank with more rejections.
+ * A sample with more attempts than this sends the rest with the next exchange(s). */
+#define BCHMC_EPS_BATCH 32
+#define BCHMC_UNIQUE_ID_BYTES 128 /* sizeof(ncclUniqueId) */
+
+typedef struct bchmc_comm bchmc_comm;
+/* Transport used by a custom communicator: all-gather `bytes_per_rank` bytes of host memory from every rank into
+ * `recv` (world * bytes_per_rank, rank order).  Returns 0 on success.  (MPI_Allgather in an MPI-launched barcode;
+ * an in-process stub in the CPU tests.) */
+typedef int (*bchmc_allgather_fn)(void *ctx, const void *send, void *recv, size_t bytes_per_rank);
+
+/* RCCL transport: rank 0 calls bchmc_comm_unique_id and hands the 128 bytes to the other ranks (a file, an
+ * environment variable, MPI_Bcast: the shim's bootstrap helper uses a file), then every rank
+ * calls bchmc_comm_create: ncclCommInitRank on `device`, a side stream and a 2 x world x 520-byte staging buffer.
+ * librccl is loaded on first use (dlopen), so single-chain runs do not depend on it. */
+int bchmc_comm_unique_id(unsigned char id[BCHMC_UNIQUE_ID_BYTES]);
+int bchmc_comm_create(const unsigned char id[BCHMC_UNIQUE_ID_BYTES], int rank, int world, int device, bchmc_comm **out);
+int bchmc_comm_create_custom(bchmc_allgather_fn fn, void *ctx, int rank, int world, bchmc_comm **out);
+void bchmc_comm_destroy(bchmc_comm *c);
+const char *bchmc_comm_last_error(const bchmc_comm *c);
+/* One exchange (ncclAllGather of 520 bytes per rank on the side stream): queue `n_mine` (>= 0) records of this rank,
+ * send the oldest <= BCHMC_EPS_BATCH queued ones, and return every rank's contribution in rank order, the own one
+ * included: all[0 .. *n_all - 1], rank_of[i] = contributing rank of all[i] (rank_of may be NULL).  `cap` = capacity of
+ * `all` (world * BCHMC_EPS_BATCH always suffices).  Every rank of the communicator must call it the same number of
+ * times. */
+int bchmc_eps_exchange(bchmc_comm *c, const bchmc_eps_record *mine, int n_mine, bchmc_eps_record *all, int *rank_of,
+                       int cap, int *n_all);
+int bchmc_comm_pending(const bchmc_comm *c); /* own records still queued for a later exchange */
 
 #ifdef __cplusplus
 }

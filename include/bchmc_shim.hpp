@@ -43,6 +43,10 @@ struct HamilNumericalView {
   ULONG Neps = 0;
   real_prec dH = 0, dK = 0, dE = 0, dprior = 0, dlikeli = 0, psi_prior = 0, psi_likeli = 0;
   real_prec psi_prior_i = 0, psi_prior_f = 0, psi_likeli_i = 0, psi_likeli_f = 0, H_kin_i = 0, H_kin_f = 0;
+  // sample bookkeeping read by the step-size schemes (struct_hamil.h:106-112): set by the caller per sample
+  ULONG iGibbs = 1;      // sample number; scheme 3's fast initial phase runs while iGibbs == 1 (time_step.cpp:141)
+  ULONG rejections = 0;  // rejected attempts of the current sample (HMC.cc:500-501)
+  bool accepted = false; // outcome of the last attempt (HMC.cc:503-504)
 };
 
 // HAMIL_DATA members used by the path (struct_hamil.h:146-222), reference names.
@@ -59,6 +63,15 @@ struct HamilView {
   real_prec *gradpsi = nullptr, *deltaX = nullptr, *posx = nullptr, *posy = nullptr, *posz = nullptr;
   int device = 0;     // HIP device of this chain
   void *engine = nullptr;  // owned by the shim: created on first use, released by release()
+  // step-size adaptation (DATA::numerical's tables and keys, struct_main.h:95-101,162-173): null = eps_fac stays
+  // (eps_fac_update_type 0).  Caller-owned (eps_adapt_create / eps_adapt_destroy).
+  struct EpsAdapt *eps = nullptr;
+  // cross-chain pooling of the step-size statistics (bchmc.h): null = single chain, the reference's behaviour
+  bchmc_comm *comm = nullptr;
+  int comm_rank = 0;
+  // generation of the input arrays as uploaded: bump with inputs_changed() where HamiltonianMC recomputes or
+  // re-reads the mass (HMC.cc:400-423); engine_for() uploads only when it differs from what the engine holds
+  unsigned long inputs_generation = 0, uploaded_generation = 0;
 };
 
 // Stand-in for gsl_rng_uniform(seed): called exactly where the reference calls it, in its order.
@@ -81,6 +94,32 @@ real_prec kinetic_term(HamilView *hd, const real_prec *momenta);  // HMC.cc:64-1
 real_prec psi(HamilView *hd, const real_prec *signal);            // HMC.cc:124-143 (stores psi_prior, psi_likeli)
 // field_statistics.cpp:20-90
 void measure_spectrum(HamilView *hd, const real_prec *signal, real_prec *kmode, real_prec *power, ULONG N_bin);
+// ---- step-size adaptation (barlib/src/hmc/leapfrog/time_step.cpp, include/hmc/leapfrog/time_step.hpp) ------------
+// The keys of data/input.par:59-87 and the two tables they act on.  Host-only, O(N_a) work per call.
+struct EpsAdapt;
+struct EpsAdaptConfig {
+  int eps_fac_update_type = 3;   // 0 none, 1 power mean every s_eps_total, 2 acceptance rate, 3 = 2 + fast initial phase
+  unsigned N_a_eps_update = 100;
+  real_prec acc_min = 0.6, acc_max = 0.7;
+  int eps_down_smooth = 5;
+  real_prec eps_up_fac = 1.;
+  real_prec eps_fac_target = 0., eps_fac_power = 2.;
+  ULONG s_eps_total = 10;
+};
+EpsAdapt *eps_adapt_create(const EpsAdaptConfig &cfg);
+void eps_adapt_destroy(EpsAdapt *e);
+// update_eps_fac (time_step.cpp:151-185): called before every trajectory (HMC.cc:453); may change n->eps_fac.
+// Returns the message the reference prints to its ncurses window ("" when nothing was adjusted).
+std::string update_eps_fac(HamilView *hd);
+// update_epsilon_acc_rate_tables (time_step.cpp:187-203): one finished attempt (n->accepted, n->epsilon) into the
+// tables.  The table index is (records - 1) % N_a with records = this chain's attempts plus pooled ones; for a single
+// chain that is the reference's (count_attempts - 1) % N_a.
+void update_epsilon_acc_rate_tables(HamilView *hd);
+// Pooled records of OTHER chains (after bchmc_eps_exchange): same tables, same index rule.
+void eps_adapt_append(EpsAdapt *e, bool accepted, real_prec epsilon);
+ULONG eps_adapt_records(const EpsAdapt *e);
+real_prec eps_adapt_acceptance_rate(const EpsAdapt *e);  // bool_mean(acc_flag_N_a), time_step.cpp:24-28
+
 // ---- HamiltonianMC on the device-resident chain (HMC.cc:431-511) -------------------------------
 // The row of performance_log.txt (HMC.cc:40-60) of one attempt.
 struct AttemptLog {
@@ -89,6 +128,10 @@ struct AttemptLog {
   ULONG Neps = 0, steps_done = 0;
   real_prec dH = 0, dK = 0, dE = 0, dprior = 0, dlikeli = 0;
   real_prec psi_prior_i = 0, psi_prior_f = 0, psi_likeli_i = 0, psi_likeli_f = 0, H_kin_i = 0, H_kin_f = 0;
+  // sample bookkeeping read by the step-size schemes (struct_hamil.h:106-112): set by the caller per sample
+  ULONG iGibbs = 1;      // sample number; scheme 3's fast initial phase runs while iGibbs == 1 (time_step.cpp:141)
+  ULONG rejections = 0;  // rejected attempts of the current sample (HMC.cc:500-501)
+  bool accepted = false; // outcome of the last attempt (HMC.cc:503-504)
 };
 // Host-side momentum draw (e.g. the caller's draw_momenta on its gsl_rng, HMC_momenta.cc:42-94): fills N doubles.
 using momenta_fn = void (*)(void *state, real_prec *momenta, ULONG N);
@@ -98,8 +141,30 @@ void chain_get_state(HamilView *hd, real_prec *x);
 // dH; Metropolis test, statement for statement HMC.cc:462-486 (a uniform is consumed only when p_acceptance < 1) }
 // until accepted or `itmax` attempts.  Momenta: `momenta` if given, else the engine's counter-based device draw
 // (seed, attempt index).  Fills log[0 .. return value - 1]; *count_attempts advances like HMC.cc:368.
+// `log` may be null; otherwise it holds `log_cap` rows and attempts beyond that are not logged (the return value still
+// counts them).  Per attempt, like the reference: update_eps_fac before the trajectory (HMC.cc:453), rejections++ on a
+// reject (500-501), n->accepted, update_epsilon_acc_rate_tables (506-507).  After the loop, when hd->comm is set, ONE
+// bchmc_eps_exchange with this sample's records; the other chains' records are appended to the tables.
 ULONG HamiltonianMC(HamilView *hd, uniform_fn uniform, void *rng_state, uint64_t seed, ULONG itmax, ULONG *count_attempts,
-                    AttemptLog *log, momenta_fn momenta, void *momenta_state);
+                    AttemptLog *log, ULONG log_cap, momenta_fn momenta, void *momenta_state);
+
+// The four engine calls HamiltonianMC makes, as a table: the default binds the C ABI (bchmc_chain_*); the CPU tests
+// bind a scripted stand-in so that the loop's bookkeeping is testable without a GPU.
+struct ChainOps {
+  int (*draw_momenta)(void *engine, uint64_t seed, uint64_t attempt);
+  int (*set_momenta)(void *engine, const real_prec *p);
+  int (*attempt)(void *engine, double eps, uint64_t neps, double *dH, double terms[6], uint64_t *steps_done);
+  int (*accept)(void *engine, int accepted);
+};
+ULONG HamiltonianMC_ops(HamilView *hd, const ChainOps &ops, void *engine, uniform_fn uniform, void *rng_state,
+                        uint64_t seed, ULONG itmax, ULONG *count_attempts, AttemptLog *log, ULONG log_cap,
+                        momenta_fn momenta, void *momenta_state);
+
+// Rank bootstrap for the RCCL transport when no launcher hands the unique id around (barcode/main.cc is a plain
+// process per GPU): rank 0 writes the 128 bytes to `path` (write to path.tmp, then rename), the others poll for it
+// (timeout_s seconds).  Sets hd->comm.
+void comm_bootstrap_file(HamilView *hd, const char *path, int rank, int world, double timeout_s);
+void comm_release(HamilView *hd);
 
 // hd's input arrays changed (HamiltonianMC recomputes the mass every sample, HMC.cc:400-423): upload them again
 void inputs_changed(HamilView *hd);
@@ -122,7 +187,26 @@ int bchmc_shim_chain_set_state(bchmc_shim::HamilView *hd, const double *x, char 
 int bchmc_shim_chain_get_state(bchmc_shim::HamilView *hd, double *x, char *err, size_t errlen);
 int bchmc_shim_HamiltonianMC(bchmc_shim::HamilView *hd, bchmc_shim::uniform_fn uniform, void *rng_state, uint64_t seed,
                              unsigned long itmax, unsigned long *count_attempts, bchmc_shim::AttemptLog *log,
-                             unsigned long *n_attempts, char *err, size_t errlen);
+                             unsigned long log_cap, unsigned long *n_attempts, char *err, size_t errlen);
+/* the same loop on a scripted engine: attempt k returns dH = script_dH[k] (CPU tests of the bookkeeping) */
+int bchmc_shim_HamiltonianMC_scripted(bchmc_shim::HamilView *hd, const double *script_dH, unsigned long n_script,
+                                      bchmc_shim::uniform_fn uniform, void *rng_state, unsigned long itmax,
+                                      unsigned long *count_attempts, bchmc_shim::AttemptLog *log, unsigned long log_cap,
+                                      unsigned long *n_attempts, char *err, size_t errlen);
+int bchmc_shim_kinetic_term(bchmc_shim::HamilView *hd, const double *momenta, double *out, char *err, size_t errlen);
+int bchmc_shim_psi(bchmc_shim::HamilView *hd, const double *signal, double *out, char *err, size_t errlen);
+bchmc_shim::EpsAdapt *bchmc_shim_eps_create(int update_type, unsigned N_a, double acc_min, double acc_max, int down_smooth,
+                                            double up_fac, double target, double power, unsigned long s_eps_total);
+void bchmc_shim_eps_destroy(bchmc_shim::EpsAdapt *e);
+void bchmc_shim_eps_append(bchmc_shim::EpsAdapt *e, int accepted, double epsilon);
+unsigned long bchmc_shim_eps_records(const bchmc_shim::EpsAdapt *e);
+double bchmc_shim_eps_acceptance_rate(const bchmc_shim::EpsAdapt *e);
+int bchmc_shim_update_eps_fac(bchmc_shim::HamilView *hd, char *msg, size_t msglen, char *err, size_t errlen);
+int bchmc_shim_update_tables(bchmc_shim::HamilView *hd, char *err, size_t errlen);
+int bchmc_shim_comm_bootstrap_file(bchmc_shim::HamilView *hd, const char *path, int rank, int world, double timeout_s,
+                                   char *err, size_t errlen);
+int bchmc_shim_comm_attach(bchmc_shim::HamilView *hd, bchmc_comm *comm); /* tests: a custom-transport communicator */
+void bchmc_shim_inputs_changed(bchmc_shim::HamilView *hd);
 size_t bchmc_shim_sizeof_attempt_log(void);
 void bchmc_shim_release(bchmc_shim::HamilView *hd);
 size_t bchmc_shim_sizeof_view(void);

@@ -1,6 +1,8 @@
-"""BASELINE-size checks on the GPU: direct oracle comparison where the oracle finishes in seconds
-(64^3, 128^3), size-independent properties at 256^3 (reversibility, Parseval/real-space energy agreement,
-mass conservation, linearity of the prior force, determinism of everything but the atomic scatter)."""
+"""BASELINE-size checks on the GPU.  Every BASELINE configuration is compared with the (OpenMP) oracle AT ITS OWN
+SIZE -- 64^3 x 10 steps (config 1), 128^3 Poissonian x 50 steps (config 2), 256^3 RSD x 3 steps + energies (config 3:
+the kernel instantiations bench.py times), 512^3 RSD with fp32 field arrays x 1 step (config 5) -- plus
+size-independent properties at 256^3 / 512^3 (reversibility, planes mode vs 3-D plans, Parseval/real-space energy
+agreement, mass conservation, linearity of the prior force, determinism of everything but the atomic scatter)."""
 import numpy as np
 import pytest
 
@@ -29,18 +31,26 @@ def test_config1_64cubed_ten_steps_against_oracle():
     e.close()
 
 
-def test_config2_128cubed_poisson_against_oracle():
-    """BASELINE config 2 shape (128^3, Poissonian likelihood) on a 2-step sample the oracle finishes quickly."""
+def test_config2_128cubed_poisson_fifty_steps_against_oracle():
+    """BASELINE config 2 at its real length: 128^3, Gaussian prior + Zel'dovich, Poissonian likelihood, 50 leapfrog
+    steps, fp64 (HMC.cc:251-369).  Tolerance re-stated for 50 steps: TOL_TRAJ_50 (see tests/util.py: the measured
+    growth of a 1e-13 perturbation of q0 over these 50 steps in the oracle itself, times the 10-step tolerance's
+    safety margin)."""
+    from tests.util import TOL_TRAJ_50
     c = Case(Nx=128, L=200.0, likelihood=0, rsd_model=0)
     c.oracle.close()
     from oracle.oracle import Oracle
     o = Oracle(c.p, omp=True)
     o.set(**c.arrays())
     e = c.engine()
-    q1o, p1o, _ = o.Hamiltonian_EoM(c.q0, c.p0, c.eps, 2)
-    q1, p1, done = e.leapfrog(c.q0, c.p0, c.eps, 2)
-    assert done == 2
-    assert rel_l2(q1, q1o) < TOL_TRAJ_10 and rel_l2(p1, p1o) < TOL_TRAJ_10
+    q1o, p1o, done_o = o.Hamiltonian_EoM(c.q0, c.p0, c.eps, 50)
+    q1, p1, done = e.leapfrog(c.q0, c.p0, c.eps, 50)
+    assert done == done_o == 50
+    assert rel_l2(q1, q1o) < TOL_TRAJ_50 and rel_l2(p1, p1o) < TOL_TRAJ_50
+    dHo, to = o.delta_Hamiltonian(c.q0, c.p0, q1o, p1o)
+    dH, t = e.delta_hamiltonian(c.q0, c.p0, q1o, p1o)
+    assert np.all(np.abs(t - to) <= TOL_ENERGY * np.abs(to))
+    o.close()
     e.close()
 
 
@@ -59,6 +69,32 @@ def big():
     e.upload(window=window, noise=noise, nobs=nobs)
     yield p, f, e, dX
     e.close()
+
+
+def test_config3_256cubed_three_steps_and_energies_against_oracle(big):
+    """BASELINE config 3 at the benchmarked size, against the oracle (OpenMP build, ~20 s of host time): the
+    instantiations bench.py times -- k_step_boundary_x<double, 512, 4>, chunk = 2048, padded rows nhp = 136, 16384
+    tiles with 64-bit record offsets -- on a 3-step trajectory (first step: 3-D plans, interior: planes mode, last:
+    3-D plans; HMC.cc:251-369) and delta_Hamiltonian (HMC.cc:209-248)."""
+    from oracle.oracle import Oracle
+    p, f, e, dX = big
+    window, noise, nobs = inputs.mock_observations(p, dX)
+    o = Oracle(p, omp=True)
+    o.set(signal_PS=f["signal_PS"], mass_f=f["mass_f"], window=window, noise=noise, nobs=nobs)
+    eps = 0.5 * p.eps_heuristic()  # the bench's step size
+    q1o, p1o, done_o = o.Hamiltonian_EoM(f["q0"], f["p0"], eps, 3)
+    q1, p1, done = e.leapfrog(f["q0"], f["p0"], eps, 3)
+    assert done == done_o == 3
+    assert rel_l2(q1, q1o) < TOL_TRAJ_10 and rel_l2(p1, p1o) < TOL_TRAJ_10
+    dHo, to = o.delta_Hamiltonian(f["q0"], f["p0"], q1o, p1o)
+    dH, t = e.delta_hamiltonian(f["q0"], f["p0"], q1o, p1o)
+    assert np.all(np.abs(t - to) <= TOL_ENERGY * np.abs(to))
+    # the force itself and the forward model's density at this size
+    g = e.gradient(f["q0"])
+    g_o = o.gradient_psi(f["q0"])[0]
+    assert rel_l2(g, g_o) < 1e-11
+    assert rel_l2(e.fetch("deltaX"), o.get("deltaX")) < 1e-12
+    o.close()
 
 
 def test_256_mass_conservation_and_overdensity(big):
@@ -165,3 +201,66 @@ def test_hundred_step_trajectory_against_oracle():
     dH, t = e.delta_hamiltonian(c.q0, c.p0, q1, p1)
     assert np.all(np.abs(t - to) <= 1e-8 * np.abs(to))
     e.close()
+
+
+@pytest.fixture(scope="module")
+def huge():
+    """BASELINE config 5: 512^3, Zel'dovich + plane-parallel RSD, Gaussian likelihood, fp32 field arrays."""
+    from barcode_amd.engine import Engine
+    p = HamilParams(Nx=512, L=200.0, likelihood=1, rsd_model=1, sfmodel=2)
+    f = inputs.make_fields(p)
+    e = Engine(p, precision=1)
+    e.upload(signal_PS=f["signal_PS"], mass_f=f["mass_f"], nobs=np.zeros(p.N), window=np.ones(p.N),
+             noise=np.ones(p.N))
+    e.forward(f["truth"], 1)
+    dX = e.fetch("deltaX").reshape((p.Nx,) * 3)
+    window, noise, nobs = inputs.mock_observations(p, dX)
+    del dX
+    e.upload(window=window, noise=noise, nobs=nobs)
+    yield p, f, e, (window, noise, nobs)
+    e.close()
+
+
+def test_config5_512cubed_fp32_one_step_against_fp64_oracle(huge):
+    """Config 5 against the oracle (fp64, OpenMP build, two force evaluations at 512^3): one leapfrog step and the
+    energies at the re-stated fp32 tolerance (rel-L2 <= 1e-4 on (q1, p1), energies <= 1e-5).  The precision
+    switch upstream is define_opt.h:46-50."""
+    from oracle.oracle import Oracle
+    p, f, e, (window, noise, nobs) = huge
+    o = Oracle(p, omp=True)
+    o.set(signal_PS=f["signal_PS"], mass_f=f["mass_f"], window=window, noise=noise, nobs=nobs)
+    eps = 0.5 * p.eps_heuristic()
+    q1o, p1o, done_o = o.Hamiltonian_EoM(f["q0"], f["p0"], eps, 1)
+    q1, p1, done = e.leapfrog(f["q0"], f["p0"], eps, 1)
+    assert done == done_o == 1
+    assert rel_l2(q1, q1o) < 1e-4 and rel_l2(p1, p1o) < 1e-4
+    K, prior, like = e.energies(q1o, p1o)
+    Ko = o.kinetic_term(p1o)
+    prior_o, like_o = o.psi(q1o)
+    o.close()
+    for a, b in ((K, Ko), (prior, prior_o), (like, like_o)):
+        assert abs(a - b) <= 1e-5 * abs(b)
+
+
+def test_512_fp32_planes_mode_reversibility_and_mass(huge, monkeypatch):
+    """Size-independent properties at 512^3 with fp32 fields: the planes-mode trajectory (k_step_boundary_x<float,
+    1024, 8>) equals the 3-D-plan one to fp32 round-off, the integrator is reversible to the fp32 level, the scatter
+    conserves mass."""
+    from barcode_amd.engine import Engine
+    p, f, e, (window, noise, nobs) = huge
+    eps = 0.5 * p.eps_heuristic()
+    q1, p1, done = e.leapfrog(f["q0"], f["p0"], eps, 4)
+    assert done == 4
+    rho = e.fetch("rho")
+    assert abs(rho.sum() * p.d ** 3 / p.N - 1.0) < 0.02 and rho.min() >= 0.0
+    del rho
+    q2, p2, done = e.leapfrog(q1, -p1, eps, 4)
+    assert rel_l2(q2, f["q0"]) < 1e-4 and rel_l2(-p2, f["p0"]) < 1e-4
+    del q2, p2
+    monkeypatch.setenv("BCHMC_NO_PLANES", "1")
+    e2 = Engine(p, precision=1)
+    e2.upload(signal_PS=f["signal_PS"], mass_f=f["mass_f"], window=window, noise=noise, nobs=nobs)
+    q3, p3, done3 = e2.leapfrog(f["q0"], f["p0"], eps, 4)
+    e2.close()
+    assert done3 == 4
+    assert rel_l2(q1, q3) < 1e-5 and rel_l2(p1, p3) < 1e-4
