@@ -119,6 +119,7 @@ struct bchmc_handle {
   void *sx = nullptr, *sy = nullptr, *sz = nullptr;            // N each: sorted positions
   int *sidx = nullptr;                                         // N: original index | flags
   bool sorted_valid = false;
+  bool cnt_clean = false;   // t_cnt[0 .. 2 ntiles] was cleared by the last k_scatter_tile81 (no fill launch needed)
   bool have_eval = false;  // rho / psi hold a forward evaluation
   int last_rsd = 0;
 
@@ -644,16 +645,19 @@ struct Pipe {
       // one-pass binning into fixed slots per tile; the two-pass kernels run only if a tile overflowed
       const int nt = h->tp.ntiles, nbricks = nblk_full(h->g.N);
       int *cnt1 = h->t_cnt, *cnt2 = h->t_cnt + nt, *ovf = h->t_cnt + 2 * nt;  // ovf[1] is sticky, see grow_sort_slots
-      HIPCHK(hipMemsetAsync(h->t_cnt, 0, (2 * (size_t)nt + 1) * sizeof(int), h->stream));
-      const int fb_grid = h->sort_direct ? std::min(nbricks, 4096) : nbricks;
+      if (!h->cnt_clean) HIPCHK(hipMemsetAsync(h->t_cnt, 0, (2 * (size_t)nt + 1) * sizeof(int), h->stream));
+      h->cnt_clean = false;
+      // the two fallback kernels return at once unless a tile overflowed: a small grid striding over the bricks keeps
+      // their launches cheap (at 256^3 the 4096-workgroup launches of two no-op kernels cost 30 us per step)
+      const int fb_grid = h->sort_direct ? std::min(nbricks, 512) : nbricks;
       if (h->sort_direct) {
         k_bin<T, true><<<nbricks, 256, 0, h->stream>>>(h->g, pp, sp, h->tp, nbricks, R(h->psi), cnt1, ovf, h->t_rank,
-                                                       R(h->sx), R(h->sy), R(h->sz), h->sidx, R(h->V));
+                                                       R(h->sx), R(h->sy), R(h->sz), h->sidx, R(h->V), h->rho_part);
       } else {
         HIPCHK(hipMemsetAsync(ovf, 1, 1, h->stream));  // non-zero flag: two-pass sort only
       }
       k_bin<T, false><<<fb_grid, 256, 0, h->stream>>>(h->g, pp, sp, h->tp, nbricks, R(h->psi), cnt2, ovf, h->t_rank,
-                                                      R(h->sx), R(h->sy), R(h->sz), h->sidx, R(h->V));
+                                                      R(h->sx), R(h->sy), R(h->sz), h->sidx, R(h->V), nullptr);
       k_scan_tiles<<<(nt + 1023) / 1024, 1024, 0, h->stream>>>(h->tp, cnt1, cnt2, ovf, h->t_off, h->t_end, h->t_woff);
       k_reorder<T><<<fb_grid, 256, 0, h->stream>>>(h->g, pp, nbricks, R(h->psi), h->t_rank, h->t_off, ovf, R(h->sx),
                                                    R(h->sy), R(h->sz), h->sidx);
@@ -665,16 +669,19 @@ struct Pipe {
       HIPCHK(hipMemsetAsync(h->rho, 0, h->g.N * sizeof(T), h->stream));
       if (h->c.mk == 3 && h->tiled) {
         // the tile kernels also leave sum(rho) in rho_part (partial sums of what they flush): no pass over rho
-        HIPCHK(hipMemsetAsync(h->rho_part, 0, kRedBlocks * sizeof(double), h->stream));
+        // (k_bin<DIRECT> has cleared the partials; without the one-pass binning a fill does)
+        if (!h->sort_direct) HIPCHK(hipMemsetAsync(h->rho_part, 0, kRedBlocks * sizeof(double), h->stream));
         const int grid = h->tp.ntiles + (int)(h->g.N / h->tp.chunk) + 1;  // upper bound on (tile, chunk) work items
         const int ncol = h->hull_exact ? h->hull_n : 0;
         // sub-cell ordering inside each work item: binary digits per axis (BCHMC_SUBSORT_BITS = 0 / 1 / 2)
         const char *sb = std::getenv("BCHMC_SUBSORT_BITS");
         const int reorder = (h->tp.chunk > 2048) ? 0 : (sb ? std::min(std::max(atoi(sb), 0), 2) : 2);
-        if (h->std81)
+        if (h->std81) {
           k_scatter_tile81<T, 12, 20><<<grid, 256, tile_lds(h, 0, sizeof(double)), h->stream>>>(
-              h->g, sp, h->tp, reorder, R(h->sx), R(h->sy), R(h->sz), h->sidx, h->t_off, h->t_end, h->t_woff, R(h->rho), h->rho_part);
-        else
+              h->g, sp, h->tp, reorder, R(h->sx), R(h->sy), R(h->sz), h->sidx, h->t_off, h->t_end, h->t_woff, R(h->rho),
+              h->rho_part, h->t_cnt, 2 * h->tp.ntiles + 1);
+          h->cnt_clean = true;
+        } else
           k_scatter_tile<T><<<grid, 256, tile_lds(h, ncol, sizeof(double)), h->stream>>>(
               h->g, sp, h->tp, h->hull, ncol, reorder, R(h->sx), R(h->sy), R(h->sz), h->sidx, h->t_off, h->t_end,
               h->t_woff, R(h->rho), h->rho_part);

@@ -112,6 +112,24 @@ __device__ __forceinline__ float fast_rsqrt(float x) {
   return fmaf(y, e, y);
 }
 
+// q = sqrt(x) together with rq = 1/sqrt(x), x > 0 and normal: hardware rsq seed (relative error e ~ 5e-8, measured
+// with scripts/rsq_accuracy.hip) + ONE third-order step  y1 = y (1 + r/2 + 3 r^2/8),  r = 1 - x y^2  (error
+// (5/16)(2e)^3 ~ 3e-22: the result is the correctly rounded one up to the roundings of the last fma, <= 1 ulp).
+// Five fp64 instructions after the rsq for q (six with rq) instead of the nine of two Newton steps + x*y + scaling
+// (scripts/valu_rates.hip: v_rsq_f64 costs 3.8 plain fp64 instructions, so the arithmetic around it is what counts).
+__device__ __forceinline__ double sqrt_rsq(double x, double &rq) {
+  const double y = __builtin_amdgcn_rsq(x);
+  const double t = x * y;
+  const double r = fma(-t, y, 1.0);
+  const double s = r * fma(r, 0.375, 0.5);
+  rq = fma(y, s, y);
+  return fma(t, s, t);
+}
+__device__ __forceinline__ float sqrt_rsq(float x, float &rq) {
+  rq = fast_rsqrt(x);
+  return x * rq;
+}
+
 template <typename T> __device__ __forceinline__ T tiny_pos();
 template <> __device__ __forceinline__ double tiny_pos<double>() { return 1e-280; }
 template <> __device__ __forceinline__ float tiny_pos<float>() { return 1e-30f; }

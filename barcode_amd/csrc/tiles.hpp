@@ -104,9 +104,12 @@ __global__ void __launch_bounds__(256)
 k_bin(Geo g, PosPar pp, SphPar sp, TilePar tp, int nbricks, const T *__restrict__ psi, int *__restrict__ cnt,
       int *__restrict__ ovf,
       int2 *__restrict__ tile_rank, T *__restrict__ sx, T *__restrict__ sy, T *__restrict__ sz, int *__restrict__ sidx,
-      T *__restrict__ V) {
+      T *__restrict__ V, double *__restrict__ zero_part) {
   constexpr int kSlots = 512;
   __shared__ int hkey[kSlots], hcnt[kSlots], hbase[kSlots];
+  // the scatter that follows accumulates sum(rho) into these partials: cleared here instead of by a fill launch
+  if (DIRECT && zero_part && blockIdx.x == 0)
+    for (int i = threadIdx.x; i < kRedBlocks; i += blockDim.x) zero_part[i] = 0.;
   if (!DIRECT && !*ovf) return;
   // DIRECT: one brick per workgroup; fallback: a small grid strides over the bricks (it usually returns above)
   for (int brick = blockIdx.x; brick < nbricks; brick += gridDim.x) {
@@ -535,9 +538,15 @@ template <typename T, int LY, int LZ>
 __global__ void __launch_bounds__(256)
 k_scatter_tile81(Geo g, SphPar sp, TilePar tp, int reorder, T *sx, T *sy, T *sz, int *sidx,
                  const long long *__restrict__ off, const long long *__restrict__ tend, const int *__restrict__ woff,
-                 T *__restrict__ rho, double *__restrict__ rho_part) {
+                 T *__restrict__ rho, double *__restrict__ rho_part, int *__restrict__ cnt_zero, int ncnt_zero) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw_scatter81[];
   double *s_tile_acc = reinterpret_cast<double *>(s_raw_scatter81);
+  // The binning counters (and its overflow flag) have been consumed by k_scan_tiles / k_reorder: clear them for the
+  // next force evaluation's k_bin here, two per workgroup, instead of with a fill launch (grid >= ntiles + 1).
+  if (threadIdx.x < 2) {
+    const int i = 2 * (int)blockIdx.x + (int)threadIdx.x;
+    if (i < ncnt_zero) cnt_zero[i] = 0;
+  }
   int tile, pb, pe;
   long long rec0;
   if (!tile_work(tp, off, tend, woff, tile, rec0, pb, pe)) return;
@@ -554,7 +563,11 @@ k_scatter_tile81(Geo g, SphPar sp, TilePar tp, int reorder, T *sx, T *sy, T *sz,
   const int tzi = tile % tp.ntz, tyi = (tile / tp.ntz) % tp.nty, txi = tile / (tp.ntz * tp.nty);
   const int ox = txi * tp.tx - 2, oy = tyi * tp.ty - 2, oz = tzi * tp.tz - 2;  // global cell of LDS (0,0,0)
   const int n = g.n;
-  const T r2_lim = (T)sp.r2_lim, h_inv = (T)sp.h_inv, w_norm = (T)sp.w_norm;
+  // Distances in units of h: r^2/h^2 = X[a] + Y[b] + Z[c] IS q^2 (no scaling per candidate), the test r/h <= 2 is
+  // q^2 <= 4 (1 + 1e-12) followed by the clamp below, W's inner branch takes q^2 from the sum it already has.
+  const T h_inv = (T)sp.h_inv, w_norm = (T)sp.w_norm, d_h = d * h_inv;
+  const T q2_lim = (T)(sp.r2_lim * sp.h_inv * sp.h_inv);
+  const T c34w = T(0.75) * w_norm, c32w = T(-1.5) * w_norm, c14w = T(0.25) * w_norm;
   for (int s = pb + threadIdx.x; s < pe; s += blockDim.x) {
     if (sidx[s] & kSortFlagNoScatter) continue;
     const T x = sx[s], y = sy[s], z = sz[s];
@@ -564,11 +577,12 @@ k_scatter_tile81(Geo g, SphPar sp, TilePar tp, int reorder, T *sx, T *sy, T *sz,
     if ((unsigned)(hx - 2) >= (unsigned)tp.tx || (unsigned)(hy - 2) >= (unsigned)tp.ty ||
         (unsigned)(hz - 2) >= (unsigned)tp.tz)
       continue;  // cannot happen (binning and this kernel see the same stored position); keeps LDS indexing safe
+    const T ux = (x - ccx) * h_inv, uy = (y - ccy) * h_inv, uz = (z - ccz) * h_inv;  // offset from the home centre
     T X[5], Y[5], Z[5];
 #pragma unroll
     for (int a = 0; a < 5; a++) {
-      const T dx = x - (ccx + (T)(a - 2) * d), dy = y - (ccy + (T)(a - 2) * d), dz = z - (ccz + (T)(a - 2) * d);
-      X[a] = dx * dx;
+      const T dx = ux - (T)(a - 2) * d_h, dy = uy - (T)(a - 2) * d_h, dz = uz - (T)(a - 2) * d_h;
+      X[a] = r_fma(dx, dx, tiny_pos<T>());  // keeps q^2 > 0 for a particle exactly on a cell centre (rsq(0) = inf)
       Y[a] = dy * dy;
       Z[a] = dz * dz;
     }
@@ -579,16 +593,22 @@ k_scatter_tile81(Geo g, SphPar sp, TilePar tp, int reorder, T *sx, T *sy, T *sz,
       for (int b = 0; b < 5; b++) {
         const int zw = hull81_zw(a, b);  // folds after unrolling
         if (zw < 0) continue;
-        const T r2ab = X[a] + Y[b];
-        if (r2ab > r2_lim) continue;
+        const T q2ab = X[a] + Y[b];
+        if (q2ab > q2_lim) continue;
         double *row = corner + LZ * (b + LY * a);
 #pragma unroll
         for (int c = 0; c < 5; c++) {
           if (c < 2 - zw || c > 2 + zw) continue;
-          const T r2 = r2ab + Z[c];
-          if (r2 <= r2_lim) {
-            const T q = (r2 * fast_rsqrt(r2 + tiny_pos<T>())) * h_inv;
-            if (q <= T(2)) atomic_add_r(row + c, (double)sph_w_folded<T>(q, w_norm));
+          const T q2 = q2ab + Z[c];
+          if (q2 <= q2_lim) {
+            T rq;
+            const T q = sqrt_rsq(q2, rq);
+            // SPH_kernel_3D (massFunctions.cc:366-384): w (1 - 3/2 q^2 + 3/4 q^3) for q <= 1, w/4 (2 - q)^3 up to
+            // q = 2; a q that rounding left a hair above 2 contributes exactly 0, like the reference's `r/h <= 2`
+            const T inner = r_fma(q2, r_fma(c34w, q, c32w), w_norm);
+            const T t = r_max(T(2) - q, T(0));
+            const T outer = (c14w * t) * (t * t);
+            atomic_add_r(row + c, (double)((q2 <= T(1)) ? inner : outer));
           }
         }
       }
@@ -654,10 +674,11 @@ k_gather_tile81(Geo g, HullPar hp, TilePar tp, int rsd, const T *__restrict__ sx
         xh[a] = dpcx - (T)(a - 2) * d_h;
         yh[a] = dpcy - (T)(a - 2) * d_h;
         zh[a] = dpcz - (T)(a - 2) * d_h;
-        X[a] = xh[a] * xh[a];
+        X[a] = r_fma(xh[a], xh[a], tiny_pos<T>());  // q^2 > 0 also for a particle exactly on a cell centre
         Y[a] = yh[a] * yh[a];
         Z[a] = zh[a] * zh[a];
       }
+      const T c225n = T(2.25) * norm, c3n = T(-3) * norm, c34n = T(-0.75) * norm;
       const T *corner = s_tile_pl + LZ * ((hy - 2) + LY * (hx - 2)) + (hz - 2);
 #pragma unroll
       for (int a = 0; a < 5; a++) {
@@ -668,12 +689,23 @@ k_gather_tile81(Geo g, HullPar hp, TilePar tp, int rsd, const T *__restrict__ sx
           const T r2ab = X[a] + Y[b];
           if (r2ab > T(4)) continue;
           const T *row = corner + LZ * (b + LY * a);
+          // the column's part_like values first: their LDS latency hides behind the first candidate's arithmetic
+          // (read where they are used, every candidate waited ~100 cycles on its own ds_read)
+          T pl[5];
+#pragma unroll
+          for (int c = 0; c < 5; c++)
+            if (c >= 2 - zw && c <= 2 + zw) pl[c] = row[c];
 #pragma unroll
           for (int c = 0; c < 5; c++) {
             if (c < 2 - zw || c > 2 + zw) continue;
             const T q_sq = r2ab + Z[c];
             if (q_sq <= T(4)) {
-              const T common = row[c] * sph_grad_folded<T>(q_sq, norm);
+              // grad_SPH_kernel_3D_h_units (SPH_kernel.cpp:148-208): dW/dq / q
+              T rq;
+              const T q = sqrt_rsq(q_sq, rq);
+              const T qm2 = q - T(2);
+              const T gr = (q_sq > T(1)) ? ((qm2 * qm2) * c34n) * rq : r_fma(c225n, q, c3n);
+              const T common = pl[c] * gr;
               vx += common * xh[a];
               vy += common * yh[b];
               vz += common * zh[c];

@@ -44,6 +44,13 @@ class EpsRecord(C.Structure):
     _fields_ = [("epsilon", C.c_double), ("accepted", C.c_int32), ("neps", C.c_int32)]
 
 
+EPS_BATCH = 32            # BCHMC_EPS_BATCH
+UNIQUE_ID_BYTES = 128     # BCHMC_UNIQUE_ID_BYTES
+PACKET_BYTES = 8 + 16 * EPS_BATCH
+# bchmc_allgather_fn: int (*)(void *ctx, const void *send, void *recv, size_t bytes_per_rank)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+
+
 class BchmcError(RuntimeError):
     """Raised for any non-zero return code; mirrors the reference's std::runtime_error."""
 
@@ -61,7 +68,9 @@ EXPORTS = ("bchmc_create", "bchmc_destroy", "bchmc_strerror", "bchmc_last_error"
            "bchmc_profile", "bchmc_profile_read", "bchmc_kernel_name",
            "bchmc_chain_set_state", "bchmc_chain_get_state", "bchmc_chain_set_momenta", "bchmc_chain_get_momenta",
            "bchmc_chain_draw_momenta", "bchmc_chain_attempt", "bchmc_chain_get_proposal", "bchmc_chain_accept",
-           "bchmc_measure_spectrum", "bchmc_philox_kat")
+           "bchmc_measure_spectrum", "bchmc_philox_kat", "bchmc_kinetic_term", "bchmc_psi",
+           "bchmc_comm_unique_id", "bchmc_comm_create", "bchmc_comm_create_custom", "bchmc_comm_destroy",
+           "bchmc_comm_last_error", "bchmc_eps_exchange", "bchmc_comm_pending")
 
 
 def load():
@@ -108,6 +117,18 @@ def load():
     lib.bchmc_chain_accept.argtypes = [vp, C.c_int]
     lib.bchmc_measure_spectrum.argtypes = [vp, dp, C.c_uint64, dp, dp]
     lib.bchmc_philox_kat.argtypes = [C.POINTER(C.c_uint32)] * 3
+    lib.bchmc_kinetic_term.argtypes = [vp, dp, dp]
+    lib.bchmc_psi.argtypes = [vp, dp, dp]
+    lib.bchmc_comm_unique_id.argtypes = [C.POINTER(C.c_ubyte)]
+    lib.bchmc_comm_create.argtypes = [C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    lib.bchmc_comm_create_custom.argtypes = [ALLGATHER_FN, vp, C.c_int, C.c_int, C.POINTER(vp)]
+    lib.bchmc_comm_destroy.argtypes = [vp]
+    lib.bchmc_comm_destroy.restype = None
+    lib.bchmc_comm_last_error.argtypes = [vp]
+    lib.bchmc_comm_last_error.restype = C.c_char_p
+    lib.bchmc_eps_exchange.argtypes = [vp, C.POINTER(EpsRecord), C.c_int, C.POINTER(EpsRecord), C.POINTER(C.c_int),
+                                       C.c_int, C.POINTER(C.c_int)]
+    lib.bchmc_comm_pending.argtypes = [vp]
     _lib = lib
     return lib
 
@@ -201,6 +222,16 @@ class Engine:
         self._chk(self.lib.bchmc_leapfrog(self.h, _p(self._in(q0)), _p(self._in(p0)), _p(q1), _p(p1), float(eps),
                                           int(neps), C.byref(done)))
         return q1, p1, done.value
+
+    def kinetic_term(self, p):
+        out = C.c_double()
+        self._chk(self.lib.bchmc_kinetic_term(self.h, _p(self._in(p)), C.byref(out)))
+        return out.value
+
+    def psi(self, q):
+        out = np.zeros(2)
+        self._chk(self.lib.bchmc_psi(self.h, _p(self._in(q)), _p(out)))
+        return out
 
     def energies(self, q, p):
         out = np.zeros(3)
@@ -300,3 +331,72 @@ class Engine:
         n = (C.c_uint64 * K_COUNT)()
         self._chk(self.lib.bchmc_profile_read(self.h, _p(ms), n))
         return {self.lib.bchmc_kernel_name(i).decode(): (float(ms[i]), int(n[i])) for i in range(K_COUNT)}
+
+
+class Comm:
+    """The cross-chain record exchange of include/bchmc.h (``bchmc_comm``): RCCL transport (``unique_id`` from rank 0)
+    or a custom host all-gather (``allgather(send_bytes) -> bytes of all ranks``; tests, MPI, torch.distributed)."""
+
+    def __init__(self, rank, world, device=0, unique_id=None, allgather=None):
+        self.lib = load()
+        self.rank, self.world = int(rank), int(world)
+        self.h = C.c_void_p()
+        self._cb = None
+        if allgather is not None or world == 1 and unique_id is None:
+            def _fn(_ctx, send, recv, nbytes):
+                try:
+                    out = allgather(C.string_at(send, nbytes))
+                    if len(out) != nbytes * self.world:
+                        return 2
+                    C.memmove(recv, out, len(out))
+                    return 0
+                except Exception:  # a Python exception must not unwind through the C caller
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            self._cb = ALLGATHER_FN(_fn) if allgather is not None else C.cast(None, ALLGATHER_FN)
+            rc = self.lib.bchmc_comm_create_custom(self._cb, None, self.rank, self.world, C.byref(self.h))
+        else:
+            buf = (C.c_ubyte * UNIQUE_ID_BYTES).from_buffer_copy(bytes(unique_id))
+            rc = self.lib.bchmc_comm_create(buf, self.rank, self.world, int(device), C.byref(self.h))
+        if rc:
+            detail = self.lib.bchmc_comm_last_error(self.h).decode() if self.h else ""
+            self.close()
+            raise BchmcError(rc, self.lib.bchmc_strerror(rc).decode(), detail)
+
+    @staticmethod
+    def unique_id():
+        lib = load()
+        buf = (C.c_ubyte * UNIQUE_ID_BYTES)()
+        rc = lib.bchmc_comm_unique_id(buf)
+        if rc:
+            raise BchmcError(rc, lib.bchmc_strerror(rc).decode(), "bchmc_comm_unique_id (is librccl loadable?)")
+        return bytes(buf)
+
+    def exchange(self, records):
+        """records: list of (epsilon, accepted, neps) of this rank's finished attempts (may be empty).
+        Returns [(rank, epsilon, accepted, neps), ...] of every rank's contribution to this exchange."""
+        n = len(records)
+        mine = (EpsRecord * max(n, 1))()
+        for i, (eps, acc, neps) in enumerate(records):
+            mine[i].epsilon, mine[i].accepted, mine[i].neps = float(eps), int(bool(acc)), int(neps)
+        cap = self.world * EPS_BATCH
+        out, who, got = (EpsRecord * cap)(), (C.c_int * cap)(), C.c_int(0)
+        rc = self.lib.bchmc_eps_exchange(self.h, mine, n, out, who, cap, C.byref(got))
+        if rc:
+            raise BchmcError(rc, self.lib.bchmc_strerror(rc).decode(), self.lib.bchmc_comm_last_error(self.h).decode())
+        return [(int(who[i]), float(out[i].epsilon), bool(out[i].accepted), int(out[i].neps)) for i in range(got.value)]
+
+    def pending(self):
+        return int(self.lib.bchmc_comm_pending(self.h))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.bchmc_comm_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

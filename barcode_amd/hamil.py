@@ -36,6 +36,8 @@ class HamilNumerical:
     H_kin_f: float = 0.0
     steps_done: int = 0
     count_attempts: int = 0
+    iGibbs: int = 1        # sample number (struct_hamil.h:106): scheme 3's fast initial phase runs while it is 1
+    rejections: int = 0    # rejected attempts of the current sample (HMC.cc:500-501)
 
 
 class HamilData:
@@ -114,7 +116,7 @@ def measure_spectrum(hd, signal=None, N_bin=200):
     return hd.engine.measure_spectrum(signal, N_bin)
 
 
-def HamiltonianMC(hd, uniform, seed=1, itmax=2000, ring=None, group=None, momenta=None):
+def HamiltonianMC(hd, uniform, seed=1, itmax=2000, ring=None, group=None, momenta=None, eps_cfg=None):
     """One sample of the reference's HamiltonianMC loop (HMC.cc:431-511) on the device-resident chain:
     repeat { draw momenta; draw (Neps, epsilon); trajectory; dH; Metropolis test } until accepted.
 
@@ -123,7 +125,13 @@ def HamiltonianMC(hd, uniform, seed=1, itmax=2000, ring=None, group=None, moment
     counter-based device generator (``seed``, attempt index) unless ``momenta`` (a callable returning a host
     array, e.g. a port of the GSL draw) is given.  The chain state must have been set with
     ``hd.engine.chain_set_state``.  Returns the list of per-attempt records (the performance-log row, HMC.cc:40-60).
+
+    Step-size bookkeeping as upstream: ``update_eps_fac`` before every trajectory (HMC.cc:453; needs ``ring`` and
+    ``eps_cfg``, a ``time_step.EpsConfig``), ``rejections`` += 1 on a reject (500-501), the attempt into the ring
+    (``update_epsilon_acc_rate_tables``, 506-507).  With a ``group``, ONE exchange after the loop -- the fixed point
+    every chain reaches once per sample -- pools the other chains' records into the ring.
     """
+    from . import time_step
     n = hd.numerical
     e = hd.engine
     log = []
@@ -133,6 +141,8 @@ def HamiltonianMC(hd, uniform, seed=1, itmax=2000, ring=None, group=None, moment
             e.chain_draw_momenta(seed, attempt)
         else:
             e.chain_set_momenta(momenta())
+        if ring is not None and eps_cfg is not None:
+            n.eps_fac = time_step.update_eps_fac(n.eps_fac, ring, eps_cfg, iGibbs=n.iGibbs, rejections=n.rejections)
         n.Neps = int(n.N_eps_fac * uniform()) + 1
         n.epsilon = float(n.eps_fac * uniform())
         if n.epsilon > 2.0:
@@ -158,16 +168,16 @@ def HamiltonianMC(hd, uniform, seed=1, itmax=2000, ring=None, group=None, moment
             accepted = uniform() < p_acceptance
         n.accepted = bool(accepted)
         e.chain_accept(accepted)
-        recs = None
+        if not accepted:
+            n.rejections += 1
         if ring is not None:
-            if group is not None:
-                recs = group.record_all(ring, n.epsilon, accepted, n.Neps)
-            else:
-                ring.record(accepted, n.epsilon)
+            ring.record(accepted, n.epsilon)
         log.append(dict(accepted=n.accepted, epsilon=n.epsilon, Neps=n.Neps, dH=n.dH, dK=n.dK, dE=n.dE,
                         dprior=n.dprior, dlikeli=n.dlikeli, psi_prior_i=n.psi_prior_i, psi_prior_f=n.psi_prior_f,
                         psi_likeli_i=n.psi_likeli_i, psi_likeli_f=n.psi_likeli_f, H_kin_i=n.H_kin_i,
-                        H_kin_f=n.H_kin_f, steps_done=done, exchanged=recs))
+                        H_kin_f=n.H_kin_f, steps_done=done, eps_fac=n.eps_fac))
         if accepted:
             break
+    if group is not None and ring is not None:
+        group.pool_into(ring, [(r["epsilon"], r["accepted"], r["Neps"]) for r in log])
     return log

@@ -18,7 +18,12 @@ _lib = None
 SHIM_EXPORTS = ("bchmc_shim_Hamiltonian_EoM", "bchmc_shim_delta_Hamiltonian", "bchmc_shim_gradient_psi",
                 "bchmc_shim_measure_spectrum", "bchmc_shim_chain_set_state", "bchmc_shim_chain_get_state",
                 "bchmc_shim_HamiltonianMC", "bchmc_shim_release", "bchmc_shim_sizeof_view",
-                "bchmc_shim_sizeof_numerical", "bchmc_shim_sizeof_attempt_log")
+                "bchmc_shim_sizeof_numerical", "bchmc_shim_sizeof_attempt_log",
+                "bchmc_shim_HamiltonianMC_scripted", "bchmc_shim_kinetic_term", "bchmc_shim_psi",
+                "bchmc_shim_eps_create", "bchmc_shim_eps_destroy", "bchmc_shim_eps_append", "bchmc_shim_eps_records",
+                "bchmc_shim_eps_acceptance_rate", "bchmc_shim_update_eps_fac", "bchmc_shim_update_tables",
+                "bchmc_shim_comm_bootstrap_file", "bchmc_shim_comm_attach", "bchmc_shim_comm_release",
+                "bchmc_shim_inputs_changed")
 
 _dp = C.POINTER(C.c_double)
 
@@ -39,6 +44,7 @@ class HamilNumericalView(C.Structure):
         ("psi_prior", C.c_double), ("psi_likeli", C.c_double),
         ("psi_prior_i", C.c_double), ("psi_prior_f", C.c_double), ("psi_likeli_i", C.c_double),
         ("psi_likeli_f", C.c_double), ("H_kin_i", C.c_double), ("H_kin_f", C.c_double),
+        ("iGibbs", C.c_ulong), ("rejections", C.c_ulong), ("accepted", C.c_bool),
     ]
 
 
@@ -52,6 +58,8 @@ class HamilView(C.Structure):
         ("signal_PS", _dp), ("mass_f", _dp), ("mass_r", _dp), ("nobs", _dp), ("noise", _dp), ("window", _dp),
         ("gradpsi", _dp), ("deltaX", _dp), ("posx", _dp), ("posy", _dp), ("posz", _dp),
         ("device", C.c_int), ("engine", C.c_void_p),
+        ("eps", C.c_void_p), ("comm", C.c_void_p), ("comm_rank", C.c_int),
+        ("inputs_generation", C.c_ulong), ("uploaded_generation", C.c_ulong),
     ]
 
 
@@ -90,7 +98,30 @@ def load():
     lib.bchmc_shim_chain_set_state.argtypes = [hv, _dp, C.c_char_p, sz]
     lib.bchmc_shim_chain_get_state.argtypes = [hv, _dp, C.c_char_p, sz]
     lib.bchmc_shim_HamiltonianMC.argtypes = [hv, UNIFORM_FN, C.c_void_p, C.c_uint64, ul, C.POINTER(ul),
-                                             C.POINTER(AttemptLog), C.POINTER(ul), C.c_char_p, sz]
+                                             C.POINTER(AttemptLog), ul, C.POINTER(ul), C.c_char_p, sz]
+    lib.bchmc_shim_HamiltonianMC_scripted.argtypes = [hv, _dp, ul, UNIFORM_FN, C.c_void_p, ul, C.POINTER(ul),
+                                                      C.POINTER(AttemptLog), ul, C.POINTER(ul), C.c_char_p, sz]
+    lib.bchmc_shim_kinetic_term.argtypes = [hv, _dp, _dp, C.c_char_p, sz]
+    lib.bchmc_shim_psi.argtypes = [hv, _dp, _dp, C.c_char_p, sz]
+    lib.bchmc_shim_eps_create.argtypes = [C.c_int, C.c_uint, C.c_double, C.c_double, C.c_int, C.c_double, C.c_double,
+                                          C.c_double, ul]
+    lib.bchmc_shim_eps_create.restype = C.c_void_p
+    lib.bchmc_shim_eps_destroy.argtypes = [C.c_void_p]
+    lib.bchmc_shim_eps_destroy.restype = None
+    lib.bchmc_shim_eps_append.argtypes = [C.c_void_p, C.c_int, C.c_double]
+    lib.bchmc_shim_eps_append.restype = None
+    lib.bchmc_shim_eps_records.argtypes = [C.c_void_p]
+    lib.bchmc_shim_eps_records.restype = ul
+    lib.bchmc_shim_eps_acceptance_rate.argtypes = [C.c_void_p]
+    lib.bchmc_shim_eps_acceptance_rate.restype = C.c_double
+    lib.bchmc_shim_update_eps_fac.argtypes = [hv, C.c_char_p, sz, C.c_char_p, sz]
+    lib.bchmc_shim_update_tables.argtypes = [hv, C.c_char_p, sz]
+    lib.bchmc_shim_comm_bootstrap_file.argtypes = [hv, C.c_char_p, C.c_int, C.c_int, C.c_double, C.c_char_p, sz]
+    lib.bchmc_shim_comm_attach.argtypes = [hv, C.c_void_p, C.c_int]
+    lib.bchmc_shim_comm_release.argtypes = [hv]
+    lib.bchmc_shim_comm_release.restype = None
+    lib.bchmc_shim_inputs_changed.argtypes = [hv]
+    lib.bchmc_shim_inputs_changed.restype = None
     lib.bchmc_shim_sizeof_attempt_log.restype = sz
     lib.bchmc_shim_release.argtypes = [hv]
     lib.bchmc_shim_release.restype = None
@@ -196,9 +227,75 @@ class ShimHamil:
         n = C.c_ulong(0)
         cb = UNIFORM_FN(lambda _state: float(uniform()))
         self._chk(self.lib.bchmc_shim_HamiltonianMC(C.byref(self.hd), cb, None, int(seed), int(itmax),
-                                                    C.byref(self.count_attempts), log, C.byref(n), self._err,
-                                                    len(self._err)))
+                                                    C.byref(self.count_attempts), log, int(itmax), C.byref(n),
+                                                    self._err, len(self._err)))
         return [{k: getattr(log[i], k) for k, _ in AttemptLog._fields_} for i in range(n.value)]
+
+    def HamiltonianMC_scripted(self, script_dH, uniform, itmax=2000, log_cap=None):
+        """The same C++ loop on a scripted engine (attempt k returns dH = script_dH[k]): bookkeeping tests, no GPU."""
+        cap = itmax if log_cap is None else int(log_cap)
+        log = (AttemptLog * max(cap, 1))()
+        n = C.c_ulong(0)
+        cb = UNIFORM_FN(lambda _state: float(uniform()))
+        sc = np.ascontiguousarray(script_dH, dtype=np.float64)
+        self._chk(self.lib.bchmc_shim_HamiltonianMC_scripted(C.byref(self.hd), _p(sc), sc.size, cb, None, int(itmax),
+                                                             C.byref(self.count_attempts),
+                                                             log if cap > 0 else None, cap, C.byref(n), self._err,
+                                                             len(self._err)))
+        return n.value, [{k: getattr(log[i], k) for k, _ in AttemptLog._fields_} for i in range(min(n.value, cap))]
+
+    def kinetic_term(self, momenta):
+        out = C.c_double(0)
+        self._chk(self.lib.bchmc_shim_kinetic_term(C.byref(self.hd), _p(self._in(momenta)), C.byref(out), self._err,
+                                                   len(self._err)))
+        return out.value
+
+    def psi(self, signal):
+        out = C.c_double(0)
+        self._chk(self.lib.bchmc_shim_psi(C.byref(self.hd), _p(self._in(signal)), C.byref(out), self._err,
+                                          len(self._err)))
+        return out.value
+
+    # ---- step-size adaptation (time_step.cpp) -------------------------------------------------------------
+    def eps_attach(self, cfg):
+        """Create the C++ EpsAdapt from a barcode_amd.time_step.EpsConfig and hang it on hd->eps."""
+        e = self.lib.bchmc_shim_eps_create(cfg.eps_fac_update_type, cfg.N_a_eps_update, cfg.acc_min, cfg.acc_max,
+                                           cfg.eps_down_smooth, cfg.eps_up_fac, cfg.eps_fac_target, cfg.eps_fac_power,
+                                           cfg.s_eps_total)
+        if not e:
+            raise ShimError("eps_adapt_create failed")
+        self.hd.eps = e
+        return e
+
+    def eps_append(self, accepted, epsilon):
+        self.lib.bchmc_shim_eps_append(self.hd.eps, int(bool(accepted)), float(epsilon))
+
+    def eps_records(self):
+        return int(self.lib.bchmc_shim_eps_records(self.hd.eps))
+
+    def eps_acceptance_rate(self):
+        return float(self.lib.bchmc_shim_eps_acceptance_rate(self.hd.eps))
+
+    def update_eps_fac(self):
+        msg = C.create_string_buffer(256)
+        self._chk(self.lib.bchmc_shim_update_eps_fac(C.byref(self.hd), msg, len(msg), self._err, len(self._err)))
+        return msg.value.decode()
+
+    def update_epsilon_acc_rate_tables(self):
+        self._chk(self.lib.bchmc_shim_update_tables(C.byref(self.hd), self._err, len(self._err)))
+
+    def comm_attach(self, comm, rank):
+        self.lib.bchmc_shim_comm_attach(C.byref(self.hd), comm, int(rank))
+
+    def comm_bootstrap_file(self, path, rank, world, timeout_s=60.0):
+        self._chk(self.lib.bchmc_shim_comm_bootstrap_file(C.byref(self.hd), path.encode(), int(rank), int(world),
+                                                          float(timeout_s), self._err, len(self._err)))
+
+    def comm_release(self):
+        self.lib.bchmc_shim_comm_release(C.byref(self.hd))
+
+    def inputs_changed(self):
+        self.lib.bchmc_shim_inputs_changed(C.byref(self.hd))
 
     def out(self, name):
         """hd->gradpsi / deltaX / posx / posy / posz as the C++ layer left them."""
@@ -206,3 +303,6 @@ class ShimHamil:
 
     def close(self):
         self.lib.bchmc_shim_release(C.byref(self.hd))
+        if self.hd.eps:
+            self.lib.bchmc_shim_eps_destroy(self.hd.eps)
+            self.hd.eps = None

@@ -473,11 +473,13 @@ int bchmc_shim_comm_bootstrap_file(bchmc_shim::HamilView *hd, const char *path, 
                                    char *err, size_t errlen) {
   return guarded(err, errlen, [&] { bchmc_shim::comm_bootstrap_file(hd, path, rank, world, timeout_s); });
 }
-int bchmc_shim_comm_attach(bchmc_shim::HamilView *hd, bchmc_comm *comm) {
+int bchmc_shim_comm_attach(bchmc_shim::HamilView *hd, bchmc_comm *comm, int rank) {
   if (!hd) return 1;
   hd->comm = comm;
+  hd->comm_rank = rank;
   return 0;
 }
+void bchmc_shim_comm_release(bchmc_shim::HamilView *hd) { bchmc_shim::comm_release(hd); }
 void bchmc_shim_inputs_changed(bchmc_shim::HamilView *hd) { bchmc_shim::inputs_changed(hd); }
 size_t bchmc_shim_sizeof_attempt_log(void) { return sizeof(bchmc_shim::AttemptLog); }
 void bchmc_shim_release(bchmc_shim::HamilView *hd) { bchmc_shim::release(hd); }

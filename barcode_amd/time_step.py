@@ -74,9 +74,12 @@ def update_eps_fac_acceptance_rate_downwards(eps_fac, ring, cfg):
     return eps_fac
 
 
-def update_eps_fac_acceptance_rate(eps_fac, ring, cfg):
-    """time_step.cpp:106-135."""
-    if ring.count_attempts % cfg.N_a_eps_update == 0 and ring.count_attempts > 0:
+def update_eps_fac_acceptance_rate(eps_fac, ring, cfg, due=None):
+    """time_step.cpp:106-135.  ``due``: the "every N_a attempts" trigger, already evaluated by the caller (crossing
+    form, see EpsRing.crossed); None evaluates the reference's equality (single chain)."""
+    if due is None:
+        due = ring.count_attempts % cfg.N_a_eps_update == 0 and ring.count_attempts > 0
+    if due:
         alpha = ring.acceptance_rate()
         if alpha < cfg.acc_min:
             eps_fac = update_eps_fac_acceptance_rate_downwards(eps_fac, ring, cfg)
@@ -87,16 +90,21 @@ def update_eps_fac_acceptance_rate(eps_fac, ring, cfg):
 
 
 def update_eps_fac(eps_fac, ring, cfg, iGibbs=2, rejections=0):
-    """time_step.cpp:151-185.  ``iGibbs`` / ``rejections`` are HAMIL_NUMERICAL's (used by scheme 3 only)."""
+    """time_step.cpp:151-185, called before every trajectory (HMC.cc:453).  ``iGibbs`` / ``rejections`` are
+    HAMIL_NUMERICAL's (used by scheme 3 only).  The "every so many attempts" triggers use the ring's crossing test, so
+    that pooled records of other chains (which advance the count by several between calls) cannot step over them;
+    for a single chain it is the reference's ``count_attempts % n == 0 && count_attempts > 0``."""
     t = cfg.eps_fac_update_type
+    every = cfg.s_eps_total if t == 1 else cfg.N_a_eps_update
+    due = ring.crossed(every)  # consumed on every call, also in the fast initial phase (which skips the test upstream)
     if t == 1:
-        if ring.count_attempts % cfg.s_eps_total == 0 and ring.count_attempts > 0:
+        if due:
             eps_fac = power_mean(eps_fac, cfg.eps_fac_target, cfg.eps_fac_power)
     elif t == 2:
-        eps_fac = update_eps_fac_acceptance_rate(eps_fac, ring, cfg)
+        eps_fac = update_eps_fac_acceptance_rate(eps_fac, ring, cfg, due)
     elif t == 3:
         if iGibbs == 1 and rejections > 0:  # fast initial phase, time_step.cpp:137-149
             eps_fac = eps_fac / 2.0
         else:
-            eps_fac = update_eps_fac_acceptance_rate(eps_fac, ring, cfg)
+            eps_fac = update_eps_fac_acceptance_rate(eps_fac, ring, cfg, due)
     return eps_fac

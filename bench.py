@@ -8,8 +8,8 @@ A "step" is one leapfrog step (HMC.cc:284-365 body: half kick, M^-1 p, drift, on
 half kick).  The timed region is ONE trajectory of exactly K steps through the C ABI
 (bchmc_leapfrog_device: state transforms + initial force + K steps + inverse transforms), with q0/p0 and all
 input grids already resident in HBM, bracketed by barrier + torch.cuda.synchronize().  Each rank runs its own
-independent chain (weak scaling); the only collective is the 16-byte/rank epsilon-statistics all-gather
-per trajectory (RCCL).  Rank 0 prints one JSON line.
+independent chain (weak scaling); the only collective is the epsilon-statistics all-gather (one 520-byte packet
+per rank per sample, bchmc_eps_exchange; RCCL).  Rank 0 prints one JSON line.
 
 `python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment launches its own N ranks: the parent
 process starts N children (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set) before it
@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--fp32", action="store_true", help="fp32 field arrays (BASELINE config 5); tolerance re-stated")
     ap.add_argument("--backend", default="nccl", help="process-group backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--exchange", default="torch", choices=["torch", "rccl"],
+                    help="transport of the per-sample epsilon-record exchange behind bchmc_eps_exchange: torch.distributed "
+                         "all_gather (default) or the library's own ncclAllGather (unique id broadcast through torch)")
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal only: every rank uses cuda:0 (never for reported numbers)")
     return ap.parse_args()
@@ -160,7 +163,12 @@ def launch_ranks(args):
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
     out0, _ = procs[0].communicate()
     rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out0.decode())
+    # exactly one JSON line on stdout: libraries of the children may have written their own chatter there
+    for line in out0.decode().splitlines():
+        if line.startswith("{"):
+            print(line)
+        elif line.strip():
+            print(line, file=sys.stderr)
     sys.stdout.flush()
     bad = [rc for rc in rcs if rc]
     if bad:
@@ -211,7 +219,8 @@ def main():
     # BASELINE config 3: "256^3, 2LPT + RSD": under rsd_model the reference dispatches to Zel'dovich + plane-parallel
     # RSD whatever sfmodel says; Gaussian likelihood, SPH kernel, calc_h 2, mass_type 1, fp64.
     params = HamilParams(Nx=args.nx, L=200.0, likelihood=args.likelihood, rsd_model=rsd, sfmodel=2 if (rsd or args.alpt) else 1)
-    group = ChainGroup(pool=True, device=dev if args.backend == "nccl" else torch.device("cpu"))
+    group = ChainGroup(pool=True, device=dev if args.backend == "nccl" else torch.device("cpu"),
+                       transport=args.exchange)
     ring = EpsRing()
 
     f = inputs.make_fields(params)
@@ -243,7 +252,7 @@ def main():
     if args.warmup > 0:
         engine.leapfrog_device(q0, p0, q1, p1, eps, args.warmup)
         engine.sync()
-    group.exchange(eps, True, args.warmup)  # untimed: first use of the collective sets up RCCL's channels
+    group.pool_into(ring, [(eps, True, args.warmup)])  # untimed: first use of the collective sets up RCCL's channels
     stream = torch.cuda.ExternalStream(engine.stream, device=dev)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
@@ -255,7 +264,8 @@ def main():
     engine.leapfrog_device(q0, p0, q1, p1, eps, args.steps)
     ev1.record(stream)
     done = engine.steps_done()  # synchronises the engine's stream
-    group.record_all(ring, eps, True, args.steps)  # the path's only collective: 16 B per rank per trajectory
+    ring.record(True, eps)
+    group.pool_into(ring, [(eps, True, args.steps)])  # the path's only collective: one 520-byte packet per rank per sample
     torch.cuda.synchronize()
     barrier()
     t1 = time.perf_counter()

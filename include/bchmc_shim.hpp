@@ -128,10 +128,6 @@ struct AttemptLog {
   ULONG Neps = 0, steps_done = 0;
   real_prec dH = 0, dK = 0, dE = 0, dprior = 0, dlikeli = 0;
   real_prec psi_prior_i = 0, psi_prior_f = 0, psi_likeli_i = 0, psi_likeli_f = 0, H_kin_i = 0, H_kin_f = 0;
-  // sample bookkeeping read by the step-size schemes (struct_hamil.h:106-112): set by the caller per sample
-  ULONG iGibbs = 1;      // sample number; scheme 3's fast initial phase runs while iGibbs == 1 (time_step.cpp:141)
-  ULONG rejections = 0;  // rejected attempts of the current sample (HMC.cc:500-501)
-  bool accepted = false; // outcome of the last attempt (HMC.cc:503-504)
 };
 // Host-side momentum draw (e.g. the caller's draw_momenta on its gsl_rng, HMC_momenta.cc:42-94): fills N doubles.
 using momenta_fn = void (*)(void *state, real_prec *momenta, ULONG N);
@@ -205,7 +201,8 @@ int bchmc_shim_update_eps_fac(bchmc_shim::HamilView *hd, char *msg, size_t msgle
 int bchmc_shim_update_tables(bchmc_shim::HamilView *hd, char *err, size_t errlen);
 int bchmc_shim_comm_bootstrap_file(bchmc_shim::HamilView *hd, const char *path, int rank, int world, double timeout_s,
                                    char *err, size_t errlen);
-int bchmc_shim_comm_attach(bchmc_shim::HamilView *hd, bchmc_comm *comm); /* tests: a custom-transport communicator */
+int bchmc_shim_comm_attach(bchmc_shim::HamilView *hd, bchmc_comm *comm, int rank); /* tests: a custom-transport communicator */
+void bchmc_shim_comm_release(bchmc_shim::HamilView *hd);
 void bchmc_shim_inputs_changed(bchmc_shim::HamilView *hd);
 size_t bchmc_shim_sizeof_attempt_log(void);
 void bchmc_shim_release(bchmc_shim::HamilView *hd);
