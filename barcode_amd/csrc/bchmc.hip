@@ -67,6 +67,8 @@ struct bchmc_handle {
   void *psi = nullptr;                               // 3 N: displacement components
   void *V = nullptr;                                 // 3 N: V components
   void *rho = nullptr, *plike = nullptr;             // N each
+  long long *rho_fix = nullptr;                      // N: fixed-point density (deterministic mode only)
+  bool fix = false;                                  // deterministic mode
   void *ioq = nullptr, *iop = nullptr;               // N each: staging / scratch
   void *gprior = nullptr, *glike = nullptr;          // N each, lazily allocated by bchmc_gradient
   void *conv = nullptr;                              // 3 N, lazily allocated for calc_h 0 / 3
@@ -666,35 +668,64 @@ struct Pipe {
     }
     {
       ProfScope ps(h, BCHMC_K_SCATTER);
-      HIPCHK(hipMemsetAsync(h->rho, 0, h->g.N * sizeof(T), h->stream));
-      if (h->c.mk == 3 && h->tiled) {
+      const bool tile_path = (h->c.mk == 3 && h->tiled);
+      // fixed point (deterministic mode): scale = 2^46 / largest single contribution (W(0) = 1/(pi h^3) for the SPH
+      // kernel, 1 for NGP / CIC / TSC weights)
+      const double fix_scale = h->c.mk == 3 ? 70368744177664. / sp.w_norm : 70368744177664.;
+      if (h->fix)
+        HIPCHK(hipMemsetAsync(h->rho_fix, 0, h->g.N * sizeof(long long), h->stream));
+      else
+        HIPCHK(hipMemsetAsync(h->rho, 0, h->g.N * sizeof(T), h->stream));
+      if (tile_path) {
         // the tile kernels also leave sum(rho) in rho_part (partial sums of what they flush): no pass over rho
         // (k_bin<DIRECT> has cleared the partials; without the one-pass binning a fill does)
-        if (!h->sort_direct) HIPCHK(hipMemsetAsync(h->rho_part, 0, kRedBlocks * sizeof(double), h->stream));
+        if (!h->sort_direct && !h->fix) HIPCHK(hipMemsetAsync(h->rho_part, 0, kRedBlocks * sizeof(double), h->stream));
         const int grid = h->tp.ntiles + (int)(h->g.N / h->tp.chunk) + 1;  // upper bound on (tile, chunk) work items
         const int ncol = h->hull_exact ? h->hull_n : 0;
         // sub-cell ordering inside each work item: binary digits per axis (BCHMC_SUBSORT_BITS = 0 / 1 / 2)
         const char *sb = std::getenv("BCHMC_SUBSORT_BITS");
         const int reorder = (h->tp.chunk > 2048) ? 0 : (sb ? std::min(std::max(atoi(sb), 0), 2) : 2);
         if (h->std81) {
-          k_scatter_tile81<T, 12, 20><<<grid, 256, tile_lds(h, 0, sizeof(double)), h->stream>>>(
-              h->g, sp, h->tp, reorder, R(h->sx), R(h->sy), R(h->sz), h->sidx, h->t_off, h->t_end, h->t_woff, R(h->rho),
-              h->rho_part, h->t_cnt, 2 * h->tp.ntiles + 1);
+          if (h->fix)
+            k_scatter_tile81<T, 12, 20, true><<<grid, 256, tile_lds(h, 0, sizeof(double)), h->stream>>>(
+                h->g, sp, h->tp, reorder, R(h->sx), R(h->sy), R(h->sz), h->sidx, h->t_off, h->t_end, h->t_woff,
+                h->rho_fix, h->rho_part, h->t_cnt, 2 * h->tp.ntiles + 1, fix_scale);
+          else
+            k_scatter_tile81<T, 12, 20, false><<<grid, 256, tile_lds(h, 0, sizeof(double)), h->stream>>>(
+                h->g, sp, h->tp, reorder, R(h->sx), R(h->sy), R(h->sz), h->sidx, h->t_off, h->t_end, h->t_woff,
+                R(h->rho), h->rho_part, h->t_cnt, 2 * h->tp.ntiles + 1, fix_scale);
           h->cnt_clean = true;
-        } else
-          k_scatter_tile<T><<<grid, 256, tile_lds(h, ncol, sizeof(double)), h->stream>>>(
+        } else if (h->fix) {
+          k_scatter_tile<T, true><<<grid, 256, tile_lds(h, ncol, sizeof(double)), h->stream>>>(
               h->g, sp, h->tp, h->hull, ncol, reorder, R(h->sx), R(h->sy), R(h->sz), h->sidx, h->t_off, h->t_end,
-              h->t_woff, R(h->rho), h->rho_part);
+              h->t_woff, h->rho_fix, h->rho_part, fix_scale);
+        } else {
+          k_scatter_tile<T, false><<<grid, 256, tile_lds(h, ncol, sizeof(double)), h->stream>>>(
+              h->g, sp, h->tp, h->hull, ncol, reorder, R(h->sx), R(h->sy), R(h->sz), h->sidx, h->t_off, h->t_end,
+              h->t_woff, R(h->rho), h->rho_part, fix_scale);
+        }
       } else if (h->c.mk == 3) {
-        k_scatter_sph<T><<<nblk_full(h->g.N), 256, 0, h->stream>>>(h->g, pp, sp, R(h->psi), R(h->rho));
+        if (h->fix)
+          k_scatter_sph<T, true><<<nblk_full(h->g.N), 256, 0, h->stream>>>(h->g, pp, sp, R(h->psi), h->rho_fix, fix_scale);
+        else
+          k_scatter_sph<T, false><<<nblk_full(h->g.N), 256, 0, h->stream>>>(h->g, pp, sp, R(h->psi), R(h->rho), fix_scale);
       } else if (h->c.mk >= 0 && h->c.mk <= 2) {
-        k_scatter_low_order<T><<<nblk_full(h->g.N), 256, 0, h->stream>>>(h->g, pp, sp, h->c.mk, R(h->psi), R(h->rho));
+        if (h->fix)
+          k_scatter_low_order<T, true><<<nblk_full(h->g.N), 256, 0, h->stream>>>(h->g, pp, sp, h->c.mk, R(h->psi),
+                                                                                 h->rho_fix, fix_scale);
+        else
+          k_scatter_low_order<T, false><<<nblk_full(h->g.N), 256, 0, h->stream>>>(h->g, pp, sp, h->c.mk, R(h->psi),
+                                                                                  R(h->rho), fix_scale);
       } else {
         return h->fail(BCHMC_ERR_ARG, "masskernel %d is not a valid value (0..3)", h->c.mk);
       }
       HIPCHK(hipGetLastError());
+      if (h->fix) {
+        k_fix_to_rho<T><<<kRedBlocks, 256, 0, h->stream>>>(h->g.N, h->rho_fix, 1. / fix_scale, R(h->rho), h->rho_part);
+        HIPCHK(hipGetLastError());
+      }
     }
-    if (!(h->c.mk == 3 && h->tiled)) {
+    if (!(h->c.mk == 3 && h->tiled) && !h->fix) {
       ProfScope ps(h, BCHMC_K_MEAN_PARTIAL);
       k_sum<T><<<kRedBlocks, 256, 0, h->stream>>>(R(h->rho), h->g.N, h->rho_part);
       HIPCHK(hipGetLastError());
@@ -1436,6 +1467,7 @@ int bchmc_create(const bchmc_config *cfg, bchmc_handle **out) {
   if (rc) return bail(rc);
   h->c = *cfg;
   h->f32 = (cfg->precision == 1);
+  h->fix = cfg->deterministic != 0 || env_on("BCHMC_DETERMINISTIC");
   h->esz = h->f32 ? sizeof(float) : sizeof(double);
   switch (cfg->mass_type) {  // struct_hamil.h:272-313
     case 0: case 6: case 60: h->mass_rs = 1; h->mass_fs = 0; break;
@@ -1589,6 +1621,7 @@ int bchmc_create(const bchmc_config *cfg, bchmc_handle **out) {
     CHK(dev_alloc_bytes(h, &h->V, 3 * N * e));
     CHK(dev_alloc_bytes(h, &h->rho, N * e));
     CHK(dev_alloc_bytes(h, &h->plike, N * e));
+    if (h->fix) CHK(dev_alloc(h, &h->rho_fix, N));
     CHK(dev_alloc_bytes(h, &h->ioq, N * e));
     CHK(dev_alloc_bytes(h, &h->iop, N * e));
     CHK(dev_alloc(h, &h->dstage, 2 * N));
@@ -1699,7 +1732,7 @@ void bchmc_destroy(bchmc_handle *h) {
   if (h->info) rocfft_execution_info_destroy(h->info);
   void *ptrs[] = {h->work,  h->wS,       h->wM,    h->qk,    h->pk,   h->gk,     h->Ck,         h->tC,   h->psi,
                   h->V,     h->rho,      h->plike, h->ioq,   h->iop,  h->gprior, h->glike,      h->conv, h->convF,
-                  h->dstage, h->cq, h->cp, h->qk2, h->pk2, h->xtw, h->part6, h->rho_part, h->partA, h->guard, h->stop, h->steps_done, h->hull,  h->t_cnt, h->t_off,
+                  h->dstage, h->rho_fix, h->cq, h->cp, h->qk2, h->pk2, h->xtw, h->part6, h->rho_part, h->partA, h->guard, h->stop, h->steps_done, h->hull,  h->t_cnt, h->t_off,
                   h->t_woff, h->t_end, h->t_rank,  h->sx,    h->sy,    h->sz,   h->sidx};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);

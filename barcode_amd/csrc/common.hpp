@@ -94,6 +94,20 @@ __device__ __forceinline__ double block_sum(double v, double *red) {
 __device__ __forceinline__ void atomic_add_r(double *p, double v) { unsafeAtomicAdd(p, v); }
 __device__ __forceinline__ void atomic_add_r(float *p, float v) { unsafeAtomicAdd(p, v); }
 
+// Deterministic mode (bchmc_config.deterministic): mass assignment accumulates in 64-bit FIXED POINT -- integer adds
+// are associative, so the density no longer depends on the order in which the atomics land (the reference announces
+// exactly this run-to-run noise for its OpenMP build, barcode/main.cc:86-90).  A contribution v becomes
+// llrint(v * scale) with scale = 2^46 / (largest possible contribution): quantisation 7e-15 of that value per
+// contribution, head-room for 2^17 maximal contributions per cell.  `cell_add` is the one accumulate primitive of all
+// mass-assignment kernels: hardware float atomics in the default mode, integer atomics here.
+__device__ __forceinline__ void cell_add(double *p, double v, double) { unsafeAtomicAdd(p, v); }
+__device__ __forceinline__ void cell_add(float *p, double v, double) { unsafeAtomicAdd(p, (float)v); }
+__device__ __forceinline__ void cell_add(long long *p, double v, double scale) {
+  atomicAdd(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double2ll_rn(v * scale));
+}
+template <bool FIX, typename T> struct Cell { using type = T; };
+template <typename T> struct Cell<true, T> { using type = long long; };
+
 // 1/sqrt(x) to ~1 ulp: hardware rsq seed + Newton steps.  Replaces the IEEE sqrt + divide pair of the
 // reference's kernel evaluations (about 35 fp64 instructions with range scaling and fix-ups); results differ
 // from the correctly rounded ones by <= 2 ulp, far inside the stated tolerance.  x must be positive and normal.

@@ -106,9 +106,10 @@ __device__ __forceinline__ bool in_domain(const Geo &g, const SphPar &sp, T x, T
 // Direct version: one thread per particle, global atomics (fallback when no tile shape divides the grid).
 // Visits the (2*reach+1)^3 cube like the reference and keeps its `r/h <= 2` decision, but rejects
 // columns/cells on squared distance before paying for sqrt and the atomic.
-template <typename T>
+template <typename T, bool FIX>
 __global__ void __launch_bounds__(256)
-k_scatter_sph(Geo g, PosPar pp, SphPar sp, const T *__restrict__ psi, T *__restrict__ rho) {
+k_scatter_sph(Geo g, PosPar pp, SphPar sp, const T *__restrict__ psi, typename Cell<FIX, T>::type *__restrict__ rho,
+              double fix_scale) {
   const long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (p >= g.N) return;
   const int k = (int)(p % g.n);
@@ -133,7 +134,7 @@ k_scatter_sph(Geo g, PosPar pp, SphPar sp, const T *__restrict__ psi, T *__restr
       const double r2ab = dx2 + dy * dy;
       if (r2ab > sp.r2_lim) continue;
       const long long ky = (iy + i2 + (long long)n * 4) % n;
-      T *row = rho + (long long)n * (ky + (long long)n * kx);
+      auto *row = rho + (long long)n * (ky + (long long)n * kx);
       for (int i3 = -R; i3 <= R; ++i3) {
         const double dz = z - (ccz + (double)i3 * d);
         const double r2 = r2ab + dz * dz;
@@ -142,7 +143,7 @@ k_scatter_sph(Geo g, PosPar pp, SphPar sp, const T *__restrict__ psi, T *__restr
         const double q = r / sp.h;
         if (q <= 2.) {
           const long long kz = (iz + i3 + (long long)n * 4) % n;
-          atomic_add_r(row + kz, (T)sph_w(q, sp.w_norm));
+          cell_add(row + kz, sph_w(q, sp.w_norm), fix_scale);
         }
       }
     }
@@ -162,6 +163,23 @@ __global__ void __launch_bounds__(256) k_sum(const T *__restrict__ a, long long 
     s += (double)a[i];
   s = block_sum(s, red);
   if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+// Deterministic mode: fixed-point density -> field array, and the kRedBlocks partial sums of the converted values
+// in a fixed order (grid = kRedBlocks workgroups, fixed cell -> workgroup map, tree reductions).
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_fix_to_rho(long long N, const long long *__restrict__ fix, double inv_scale, T *__restrict__ rho,
+             double *__restrict__ partials) {
+  __shared__ double red[4];
+  double acc = 0.;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < N; i += (long long)gridDim.x * blockDim.x) {
+    const T v = (T)((double)fix[i] * inv_scale);
+    rho[i] = v;
+    acc += (double)v;
+  }
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) partials[blockIdx.x] = acc;
 }
 
 // Sum of the kRedBlocks partials, identical in every block that calls it (deterministic order).

@@ -358,14 +358,27 @@ __device__ __forceinline__ void subsort_subcell(int bits, int pb, int pe, T inv_
   __threadfence_block();
 }
 
-// getDensity_SPH on sorted particles: LDS accumulation per (tile, chunk), one flush.
+// One LDS cell of a work item into the global density; returns what the default mode adds to its running sum(rho).
 template <typename T>
+__device__ __forceinline__ double flush_cell(T *dst, double v) {
+  atomic_add_r(dst, (T)v);
+  return (double)(T)v;
+}
+__device__ __forceinline__ double flush_cell(long long *dst, long long v) {
+  atomicAdd(reinterpret_cast<unsigned long long *>(dst), (unsigned long long)v);
+  return 0.;
+}
+
+// getDensity_SPH on sorted particles: LDS accumulation per (tile, chunk), one flush.
+template <typename T, bool FIX>
 __global__ void __launch_bounds__(256)
 k_scatter_tile(Geo g, SphPar sp, TilePar tp, const int4 *__restrict__ cols, int ncol, int reorder, T *sx, T *sy, T *sz,
                int *sidx, const long long *__restrict__ off, const long long *__restrict__ tend, const int *__restrict__ woff,
-               T *__restrict__ rho, double *__restrict__ rho_part) {
+               typename Cell<FIX, T>::type *__restrict__ rho, double *__restrict__ rho_part, double fix_scale) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw_scatter[];
-  double *s_tile_acc = reinterpret_cast<double *>(s_raw_scatter);  // accumulate in double also for float fields
+  // accumulate in double also for float fields (fixed point in deterministic mode)
+  using Acc = typename Cell<FIX, double>::type;
+  Acc *s_tile_acc = reinterpret_cast<Acc *>(s_raw_scatter);
   int tile, pb, pe;
   long long rec0;
   if (!tile_work(tp, off, tend, woff, tile, rec0, pb, pe)) return;
@@ -376,7 +389,7 @@ k_scatter_tile(Geo g, SphPar sp, TilePar tp, const int4 *__restrict__ cols, int 
   const int ncell = tp.lx * tp.ly * tp.lz;
   int4 *s_cols = reinterpret_cast<int4 *>(s_raw_scatter + (((size_t)ncell * sizeof(double) + 15) & ~(size_t)15));
   for (int m = threadIdx.x; m < ncol; m += blockDim.x) s_cols[m] = cols[m];
-  for (int c = threadIdx.x; c < ncell; c += blockDim.x) s_tile_acc[c] = 0.;
+  for (int c = threadIdx.x; c < ncell; c += blockDim.x) s_tile_acc[c] = Acc(0);
   const T d = (T)g.d;
   const HomeCell<T> hc = make_home<T>(g);
   if (reorder) subsort_subcell<T>(reorder, pb, pe, hc.inv_d, sx, sy, sz, sidx);
@@ -402,13 +415,13 @@ k_scatter_tile(Geo g, SphPar sp, TilePar tp, const int4 *__restrict__ cols, int 
         const T dy = y - (ccy + (T)c.y * d);
         const T r2ab = dx * dx + dy * dy;
         if (r2ab > r2_lim) continue;
-        double *row = s_tile_acc + tp.lz * ((hy + c.y) + tp.ly * (hx + c.x)) + hz;
+        Acc *row = s_tile_acc + tp.lz * ((hy + c.y) + tp.ly * (hx + c.x)) + hz;
         for (int i3 = c.z; i3 <= c.w; ++i3) {
           const T dz = z - (ccz + (T)i3 * d);
           const T r2 = r2ab + dz * dz;
           if (r2 <= r2_lim) {
             const T q = (r2 * fast_rsqrt(r2 + tiny_pos<T>())) * h_inv;
-            if (q <= T(2)) atomic_add_r(row + i3, (double)sph_w_folded<T>(q, w_norm));
+            if (q <= T(2)) cell_add(row + i3, (double)sph_w_folded<T>(q, w_norm), fix_scale);
           }
         }
       }
@@ -421,13 +434,13 @@ k_scatter_tile(Geo g, SphPar sp, TilePar tp, const int4 *__restrict__ cols, int 
           const T dy = y - (ccy + (T)i2 * d);
           const T r2ab = dx2 + dy * dy;
           if (r2ab > r2_lim) continue;
-          double *row = s_tile_acc + tp.lz * ((hy + i2) + tp.ly * (hx + i1)) + hz;
+          Acc *row = s_tile_acc + tp.lz * ((hy + i2) + tp.ly * (hx + i1)) + hz;
           for (int i3 = -R; i3 <= R; ++i3) {
             const T dz = z - (ccz + (T)i3 * d);
             const T r2 = r2ab + dz * dz;
             if (r2 > r2_lim) continue;
             const T q = (r2 * fast_rsqrt(r2 + tiny_pos<T>())) * h_inv;
-            if (q <= T(2)) atomic_add_r(row + i3, (double)sph_w_folded<T>(q, w_norm));
+            if (q <= T(2)) cell_add(row + i3, (double)sph_w_folded<T>(q, w_norm), fix_scale);
           }
         }
       }
@@ -436,17 +449,18 @@ k_scatter_tile(Geo g, SphPar sp, TilePar tp, const int4 *__restrict__ cols, int 
   __syncthreads();
   double flushed = 0.;  // sum of everything this work item adds to rho: the mean density needs no pass over rho
   for (int c = threadIdx.x; c < ncell; c += blockDim.x) {
-    const double v = s_tile_acc[c];
-    if (v != 0.) {
-      flushed += (double)(T)v;
+    const Acc v = s_tile_acc[c];
+    if (v != Acc(0)) {
       const int cz = c % tp.lz, cy = (c / tp.lz) % tp.ly, cx = c / (tp.lz * tp.ly);
       const int gx = (ox + cx + n) % n, gy = (oy + cy + n) % n, gz = (oz + cz + n) % n;
-      atomic_add_r(rho + gz + (long long)n * (gy + (long long)n * gx), (T)v);
+      flushed += flush_cell(rho + gz + (long long)n * (gy + (long long)n * gx), v);
     }
   }
-  __shared__ double s_red_flush[4];
-  flushed = block_sum(flushed, s_red_flush);
-  if (threadIdx.x == 0 && flushed != 0.) atomic_add_r(rho_part + (blockIdx.x & (kRedBlocks - 1)), flushed);
+  if (!FIX) {  // deterministic mode: k_fix_to_rho sums the converted field in a fixed order instead
+    __shared__ double s_red_flush[4];
+    flushed = block_sum(flushed, s_red_flush);
+    if (threadIdx.x == 0 && flushed != 0.) atomic_add_r(rho_part + (blockIdx.x & (kRedBlocks - 1)), flushed);
+  }
 }
 
 // likelihood_calc_V_SPH on sorted particles: part_like tile + halo staged in LDS.
@@ -534,13 +548,25 @@ __host__ __device__ constexpr int hull81_zw(int a, int b) {
   return (i1 == 2 && i2 == 2) ? -1 : ((i1 == 2 || i2 == 2) ? 1 : 2);
 }
 
-template <typename T, int LY, int LZ>
-__global__ void __launch_bounds__(256)
+// Register budgets (waves per SIMD the compiler must leave room for), A/B'd at 256^3 fp64 on one box
+// (gpurun_out/ab*.json, r02): scatter 4 / 5 / 6 waves -> 1.042 / 0.997 / 0.983 ms per launch (6 waves = 80 VGPRs spills
+// a few of the sub-cell sort's record registers, and still wins: the kernel is stall-bound at 71 % VALU busy);
+// gather 5 / 6 -> 0.966 / 1.12 ms (its spills land in the candidate loop).
+#ifndef BCHMC_SCATTER_WAVES
+#define BCHMC_SCATTER_WAVES 6
+#endif
+#ifndef BCHMC_GATHER_WAVES
+#define BCHMC_GATHER_WAVES 5
+#endif
+template <typename T, int LY, int LZ, bool FIX>
+__global__ void __launch_bounds__(256, BCHMC_SCATTER_WAVES)
 k_scatter_tile81(Geo g, SphPar sp, TilePar tp, int reorder, T *sx, T *sy, T *sz, int *sidx,
                  const long long *__restrict__ off, const long long *__restrict__ tend, const int *__restrict__ woff,
-                 T *__restrict__ rho, double *__restrict__ rho_part, int *__restrict__ cnt_zero, int ncnt_zero) {
+                 typename Cell<FIX, T>::type *__restrict__ rho, double *__restrict__ rho_part, int *__restrict__ cnt_zero,
+                 int ncnt_zero, double fix_scale) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw_scatter81[];
-  double *s_tile_acc = reinterpret_cast<double *>(s_raw_scatter81);
+  using Acc = typename Cell<FIX, double>::type;
+  Acc *s_tile_acc = reinterpret_cast<Acc *>(s_raw_scatter81);
   // The binning counters (and its overflow flag) have been consumed by k_scan_tiles / k_reorder: clear them for the
   // next force evaluation's k_bin here, two per workgroup, instead of with a fill launch (grid >= ntiles + 1).
   if (threadIdx.x < 2) {
@@ -555,7 +581,7 @@ k_scatter_tile81(Geo g, SphPar sp, TilePar tp, int reorder, T *sx, T *sy, T *sz,
   sz += rec0;
   sidx += rec0;
   const int ncell = tp.lx * LY * LZ;
-  for (int c = threadIdx.x; c < ncell; c += blockDim.x) s_tile_acc[c] = 0.;
+  for (int c = threadIdx.x; c < ncell; c += blockDim.x) s_tile_acc[c] = Acc(0);
   const T d = (T)g.d;
   const HomeCell<T> hc = make_home<T>(g);
   if (reorder) subsort_subcell<T>(reorder, pb, pe, hc.inv_d, sx, sy, sz, sidx);
@@ -586,7 +612,7 @@ k_scatter_tile81(Geo g, SphPar sp, TilePar tp, int reorder, T *sx, T *sy, T *sz,
       Y[a] = dy * dy;
       Z[a] = dz * dz;
     }
-    double *corner = s_tile_acc + LZ * ((hy - 2) + LY * (hx - 2)) + (hz - 2);
+    Acc *corner = s_tile_acc + LZ * ((hy - 2) + LY * (hx - 2)) + (hz - 2);
 #pragma unroll
     for (int a = 0; a < 5; a++) {
 #pragma unroll
@@ -595,7 +621,7 @@ k_scatter_tile81(Geo g, SphPar sp, TilePar tp, int reorder, T *sx, T *sy, T *sz,
         if (zw < 0) continue;
         const T q2ab = X[a] + Y[b];
         if (q2ab > q2_lim) continue;
-        double *row = corner + LZ * (b + LY * a);
+        Acc *row = corner + LZ * (b + LY * a);
 #pragma unroll
         for (int c = 0; c < 5; c++) {
           if (c < 2 - zw || c > 2 + zw) continue;
@@ -608,7 +634,7 @@ k_scatter_tile81(Geo g, SphPar sp, TilePar tp, int reorder, T *sx, T *sy, T *sz,
             const T inner = r_fma(q2, r_fma(c34w, q, c32w), w_norm);
             const T t = r_max(T(2) - q, T(0));
             const T outer = (c14w * t) * (t * t);
-            atomic_add_r(row + c, (double)((q2 <= T(1)) ? inner : outer));
+            cell_add(row + c, (double)((q2 <= T(1)) ? inner : outer), fix_scale);
           }
         }
       }
@@ -617,21 +643,22 @@ k_scatter_tile81(Geo g, SphPar sp, TilePar tp, int reorder, T *sx, T *sy, T *sz,
   __syncthreads();
   double flushed = 0.;  // sum of everything this work item adds to rho: the mean density needs no pass over rho
   for (int c = threadIdx.x; c < ncell; c += blockDim.x) {
-    const double v = s_tile_acc[c];
-    if (v != 0.) {
-      flushed += (double)(T)v;
+    const Acc v = s_tile_acc[c];
+    if (v != Acc(0)) {
       const int cz = c % LZ, cy = (c / LZ) % LY, cx = c / (LZ * LY);
       const int gx = (ox + cx + n) % n, gy = (oy + cy + n) % n, gz = (oz + cz + n) % n;
-      atomic_add_r(rho + gz + (long long)n * (gy + (long long)n * gx), (T)v);
+      flushed += flush_cell(rho + gz + (long long)n * (gy + (long long)n * gx), v);
     }
   }
-  __shared__ double s_red_flush[4];
-  flushed = block_sum(flushed, s_red_flush);
-  if (threadIdx.x == 0 && flushed != 0.) atomic_add_r(rho_part + (blockIdx.x & (kRedBlocks - 1)), flushed);
+  if (!FIX) {  // deterministic mode: k_fix_to_rho sums the converted field in a fixed order instead
+    __shared__ double s_red_flush[4];
+    flushed = block_sum(flushed, s_red_flush);
+    if (threadIdx.x == 0 && flushed != 0.) atomic_add_r(rho_part + (blockIdx.x & (kRedBlocks - 1)), flushed);
+  }
 }
 
 template <typename T, int LY, int LZ>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, BCHMC_GATHER_WAVES)
 k_gather_tile81(Geo g, HullPar hp, TilePar tp, int rsd, const T *__restrict__ sx, const T *__restrict__ sy,
                 const T *__restrict__ sz, const int *__restrict__ sidx, const long long *__restrict__ off,
                 const long long *__restrict__ tend, const int *__restrict__ woff, const T *__restrict__ plike,

@@ -11,9 +11,10 @@ namespace bchmc {
 // One thread per particle, 1 / 8 / 27 global atomics.  Index and weight formulas are the reference's,
 // including the cell-centred CIC shift (x - d/2 wrapped) and TSC's inclusive `<= min + L` domain test.
 // ------------------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, bool FIX>
 __global__ void __launch_bounds__(256)
-k_scatter_low_order(Geo g, PosPar pp, SphPar sp, int mk, const T *__restrict__ psi, T *__restrict__ rho) {
+k_scatter_low_order(Geo g, PosPar pp, SphPar sp, int mk, const T *__restrict__ psi,
+                    typename Cell<FIX, T>::type *__restrict__ rho, double fix_scale) {
   const long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (p >= g.N) return;
   const int n = g.n;
@@ -35,7 +36,7 @@ k_scatter_low_order(Geo g, PosPar pp, SphPar sp, int mk, const T *__restrict__ p
   if (mk == 0) {
     const unsigned ci = (unsigned)floor((x - sp.min1) / d) % n, cj = (unsigned)floor((y - sp.min2) / d) % n,
                    ck = (unsigned)floor((z - sp.min3) / d) % n;
-    atomic_add_r(RHO_AT(ci, cj, ck), T(1));
+    cell_add(RHO_AT(ci, cj, ck), 1., fix_scale);
   } else if (mk == 1) {
     double q[3] = {x - 0.5 * d, y - 0.5 * d, z - 0.5 * d};
     long long c1[3], c2[3];
@@ -50,14 +51,14 @@ k_scatter_low_order(Geo g, PosPar pp, SphPar sp, int mk, const T *__restrict__ p
       tx[a] = 1. - dx[a];
     }
     const double mass = 1.;
-    atomic_add_r(RHO_AT(c1[0], c1[1], c1[2]), (T)(mass * tx[0] * tx[1] * tx[2]));
-    atomic_add_r(RHO_AT(c2[0], c1[1], c1[2]), (T)(mass * dx[0] * tx[1] * tx[2]));
-    atomic_add_r(RHO_AT(c1[0], c2[1], c1[2]), (T)(mass * tx[0] * dx[1] * tx[2]));
-    atomic_add_r(RHO_AT(c1[0], c1[1], c2[2]), (T)(mass * tx[0] * tx[1] * dx[2]));
-    atomic_add_r(RHO_AT(c2[0], c2[1], c1[2]), (T)(mass * dx[0] * dx[1] * tx[2]));
-    atomic_add_r(RHO_AT(c2[0], c1[1], c2[2]), (T)(mass * dx[0] * tx[1] * dx[2]));
-    atomic_add_r(RHO_AT(c1[0], c2[1], c2[2]), (T)(mass * tx[0] * dx[1] * dx[2]));
-    atomic_add_r(RHO_AT(c2[0], c2[1], c2[2]), (T)(mass * dx[0] * dx[1] * dx[2]));
+    cell_add(RHO_AT(c1[0], c1[1], c1[2]), (double)(T)(mass * tx[0] * tx[1] * tx[2]), fix_scale);
+    cell_add(RHO_AT(c2[0], c1[1], c1[2]), (double)(T)(mass * dx[0] * tx[1] * tx[2]), fix_scale);
+    cell_add(RHO_AT(c1[0], c2[1], c1[2]), (double)(T)(mass * tx[0] * dx[1] * tx[2]), fix_scale);
+    cell_add(RHO_AT(c1[0], c1[1], c2[2]), (double)(T)(mass * tx[0] * tx[1] * dx[2]), fix_scale);
+    cell_add(RHO_AT(c2[0], c2[1], c1[2]), (double)(T)(mass * dx[0] * dx[1] * tx[2]), fix_scale);
+    cell_add(RHO_AT(c2[0], c1[1], c2[2]), (double)(T)(mass * dx[0] * tx[1] * dx[2]), fix_scale);
+    cell_add(RHO_AT(c1[0], c2[1], c2[2]), (double)(T)(mass * tx[0] * dx[1] * dx[2]), fix_scale);
+    cell_add(RHO_AT(c2[0], c2[1], c2[2]), (double)(T)(mass * dx[0] * dx[1] * dx[2]), fix_scale);
   } else {
     const double pos[3] = {(x - sp.min1) / d, (y - sp.min2) / d, (z - sp.min3) / d};
     unsigned c[3][3];
@@ -78,7 +79,7 @@ k_scatter_low_order(Geo g, PosPar pp, SphPar sp, int mk, const T *__restrict__ p
 #pragma unroll
       for (int b = 0; b < 3; b++)
 #pragma unroll
-        for (int e = 0; e < 3; e++) atomic_add_r(RHO_AT(c[0][a], c[1][b], c[2][e]), (T)(1. * w[0][a] * w[1][b] * w[2][e]));
+        for (int e = 0; e < 3; e++) cell_add(RHO_AT(c[0][a], c[1][b], c[2][e]), (double)(T)(1. * w[0][a] * w[1][b] * w[2][e]), fix_scale);
   }
 #undef RHO_AT
 }

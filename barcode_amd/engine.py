@@ -12,8 +12,9 @@ import numpy as np
 import torch  # noqa: F401  (must precede loading libbarcode_hip.so, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbarcode_hip.so")
-ABI_VERSION = 2
+# BCHMC_LIB: an alternative build of the same library (A/B runs of kernel variants on one box)
+LIB_PATH = os.environ.get("BCHMC_LIB") or os.path.join(_HERE, "libbarcode_hip.so")
+ABI_VERSION = 3
 
 FIELDS = dict(signal_PS=0, mass_f=1, mass_r=2, nobs=3, noise=4, window=5, deltaX=6, posx=7, posy=8, posz=9,
               rho=10, part_like=11, Vx=12, Vy=13, Vz=14, psix=15, psiy=16, psiz=17, grad_prior=18, grad_like=19)
@@ -36,7 +37,7 @@ class BchmcConfig(C.Structure):
         ("rho_c", C.c_double), ("delta_min", C.c_double), ("biasP", C.c_double), ("biasE", C.c_double),
         ("ascale", C.c_double), ("D1", C.c_double), ("D2", C.c_double), ("OM", C.c_double), ("OL", C.c_double),
         ("kth", C.c_double),
-        ("precision", C.c_int32), ("device", C.c_int32),
+        ("precision", C.c_int32), ("device", C.c_int32), ("deterministic", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 
@@ -145,17 +146,18 @@ def philox_kat(ctr, key):
     return [int(x) for x in o]
 
 
-def make_config(params, device=0, precision=0):
+def make_config(params, device=0, precision=0, deterministic=0):
     cfg = BchmcConfig()
     cfg.abi_version = ABI_VERSION
     cfg.Nx = int(params.Nx)
     cfg.L = float(params.L)
     for name, _ in BchmcConfig._fields_:
-        if name in ("abi_version", "Nx", "L", "precision", "device"):
+        if name in ("abi_version", "Nx", "L", "precision", "device", "deterministic", "reserved0"):
             continue
         setattr(cfg, name, getattr(params, name))
     cfg.precision = int(precision)
     cfg.device = int(device)
+    cfg.deterministic = int(deterministic)
     return cfg
 
 
@@ -167,16 +169,16 @@ def _p(a):
 class Engine:
     """One chain on one GPU: owns a ``bchmc_handle``."""
 
-    def __init__(self, params, device=0, precision=0):
+    def __init__(self, params, device=0, precision=0, deterministic=0):
         """precision 0: fp64 field arrays (reference DOUBLE_PREC); 1: fp32 field arrays (BASELINE config 5).
-        Host arrays are float64 either way."""
+        Host arrays are float64 either way.  deterministic 1: bitwise repeatable mass assignment (fixed point)."""
         self.lib = load()
         self.precision = int(precision)
         self.params = params
         self.Nx = int(params.Nx)
         self.N = self.Nx ** 3
         self.h = C.c_void_p()
-        cfg = make_config(params, device, precision)
+        cfg = make_config(params, device, precision, deterministic)
         rc = self.lib.bchmc_create(C.byref(cfg), C.byref(self.h))
         if rc:
             detail = self.lib.bchmc_last_error(self.h).decode() if self.h else ""

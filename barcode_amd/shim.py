@@ -59,7 +59,7 @@ class HamilView(C.Structure):
         ("gradpsi", _dp), ("deltaX", _dp), ("posx", _dp), ("posy", _dp), ("posz", _dp),
         ("device", C.c_int), ("engine", C.c_void_p),
         ("eps", C.c_void_p), ("comm", C.c_void_p), ("comm_rank", C.c_int),
-        ("inputs_generation", C.c_ulong), ("uploaded_generation", C.c_ulong),
+        ("inputs_generation", C.c_ulong), ("uploaded_generation", C.c_ulong), ("deterministic", C.c_int),
     ]
 
 

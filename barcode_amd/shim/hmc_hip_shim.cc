@@ -66,6 +66,7 @@ bchmc_handle *engine_for(HamilView *hd) {
   c.kth = n->kth;
   c.precision = 0;
   c.device = hd->device;
+  c.deterministic = hd->deterministic;
   bchmc_handle *h = nullptr;
   const int rc = bchmc_create(&c, &h);
   if (rc) {

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define BCHMC_ABI_VERSION 2
+#define BCHMC_ABI_VERSION 3
 
 /* Scalars of HAMIL_NUMERICAL / HAMIL_DATA read by the path (barlib/include/struct_hamil.h:51-222);
  * filled by the shim from the HAMIL_DATA that call_hamil.cc:42 builds.  Cubic grids only, like the
@@ -50,6 +50,12 @@ typedef struct bchmc_config {
                               * storage + particle-mesh arithmetic in float, k-space arithmetic and reductions in
                               * double).  The ABI's arrays are double in both modes. */
   int32_t device;            /* HIP device ordinal */
+  int32_t deterministic;     /* 1: bitwise repeatable results -- the mass assignment accumulates in 64-bit fixed point
+                              * (integer adds are order-independent), the density is converted and summed in a fixed
+                              * order; one extra pass over the grid per force evaluation.  0: hardware float atomics,
+                              * last bits vary from run to run like the reference's OpenMP build (barcode/main.cc:86-90).
+                              * BCHMC_DETERMINISTIC=1 in the environment switches it on for every handle. */
+  int32_t reserved0;
 } bchmc_config;
 
 enum {

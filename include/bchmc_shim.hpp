@@ -72,6 +72,7 @@ struct HamilView {
   // generation of the input arrays as uploaded: bump with inputs_changed() where HamiltonianMC recomputes or
   // re-reads the mass (HMC.cc:400-423); engine_for() uploads only when it differs from what the engine holds
   unsigned long inputs_generation = 0, uploaded_generation = 0;
+  int deterministic = 0;  // bchmc_config.deterministic: bitwise repeatable mass assignment (fixed point)
 };
 
 // Stand-in for gsl_rng_uniform(seed): called exactly where the reference calls it, in its order.
