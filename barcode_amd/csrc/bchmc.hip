@@ -115,7 +115,10 @@ struct bchmc_handle {
   double alpt_wtot = 0.;     // kernelcomp's normalisation (sum of the real-space kernel), computed on first use
   bool std81 = false;  // standard 81-cell hull on 8 x 8 x 16 tiles with halo 2: fully unrolled scatter/gather kernels
   TilePar tp{};
-  int *t_cnt = nullptr, *t_woff = nullptr;   // 2 ntiles + 2 (one-pass counts, fallback counts, overflow flags), ntiles + 1
+  int *t_cnt = nullptr, *t_woff = nullptr;   // 9 ntiles + 2 (one-pass counts per (tile, octant), fallback counts per tile,
+                                             // overflow flags), ntiles + 1
+  int4 *t_oct = nullptr;                     // 2 ntiles: octant segment starts of every tile (k_scan_tiles)
+  int *t_seg = nullptr;                      // 1: slots per octant segment of the current sort, 0 = contiguous records
   long long *t_off = nullptr, *t_end = nullptr;  // ntiles each: record range of every tile (ntiles * cap can pass 2^31)
   int2 *t_rank = nullptr;                                      // N
   void *sx = nullptr, *sy = nullptr, *sz = nullptr;            // N each: sorted positions
@@ -358,7 +361,7 @@ int check_inputs(bchmc_handle *h) {
 // they would no longer be addressable / allocatable.  Called at the start of every trajectory and forward model.
 int grow_sort_slots(bchmc_handle *h) {
   if (!h->tiled || !h->sort_direct) return BCHMC_OK;
-  int *sticky = h->t_cnt + 2 * (size_t)h->tp.ntiles + 1;
+  int *sticky = h->t_cnt + (kOct + 1) * (size_t)h->tp.ntiles + 1;
   int seen = 0;
   HIPCHK(hipMemcpyAsync(&seen, sticky, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -646,21 +649,22 @@ struct Pipe {
       ProfScope ps(h, BCHMC_K_SORT);
       // one-pass binning into fixed slots per tile; the two-pass kernels run only if a tile overflowed
       const int nt = h->tp.ntiles, nbricks = nblk_full(h->g.N);
-      int *cnt1 = h->t_cnt, *cnt2 = h->t_cnt + nt, *ovf = h->t_cnt + 2 * nt;  // ovf[1] is sticky, see grow_sort_slots
-      if (!h->cnt_clean) HIPCHK(hipMemsetAsync(h->t_cnt, 0, (2 * (size_t)nt + 1) * sizeof(int), h->stream));
+      int *cnt1 = h->t_cnt, *cnt2 = h->t_cnt + kOct * nt, *ovf = h->t_cnt + (kOct + 1) * nt;  // ovf[1] is sticky, see grow_sort_slots
+      if (!h->cnt_clean) HIPCHK(hipMemsetAsync(h->t_cnt, 0, ((kOct + 1) * (size_t)nt + 1) * sizeof(int), h->stream));
       h->cnt_clean = false;
       // the two fallback kernels return at once unless a tile overflowed: a small grid striding over the bricks keeps
       // their launches cheap (at 256^3 the 4096-workgroup launches of two no-op kernels cost 30 us per step)
       const int fb_grid = h->sort_direct ? std::min(nbricks, 512) : nbricks;
       if (h->sort_direct) {
-        k_bin<T, true><<<nbricks, 256, 0, h->stream>>>(h->g, pp, sp, h->tp, nbricks, R(h->psi), cnt1, ovf, h->t_rank,
-                                                       R(h->sx), R(h->sy), R(h->sz), h->sidx, R(h->V), h->rho_part);
+        const int nsuper = (nbricks + kBinPer - 1) / kBinPer;
+        k_bin_direct<T><<<nsuper, 256, 0, h->stream>>>(h->g, pp, sp, h->tp, nsuper, R(h->psi), cnt1, ovf, R(h->sx),
+                                                       R(h->sy), R(h->sz), h->sidx, R(h->V), h->rho_part);
       } else {
         HIPCHK(hipMemsetAsync(ovf, 1, 1, h->stream));  // non-zero flag: two-pass sort only
       }
-      k_bin<T, false><<<fb_grid, 256, 0, h->stream>>>(h->g, pp, sp, h->tp, nbricks, R(h->psi), cnt2, ovf, h->t_rank,
-                                                      R(h->sx), R(h->sy), R(h->sz), h->sidx, R(h->V), nullptr);
-      k_scan_tiles<<<(nt + 1023) / 1024, 1024, 0, h->stream>>>(h->tp, cnt1, cnt2, ovf, h->t_off, h->t_end, h->t_woff);
+      k_bin<T><<<fb_grid, 256, 0, h->stream>>>(h->g, pp, sp, h->tp, nbricks, R(h->psi), cnt2, ovf, h->t_rank, R(h->V));
+      k_scan_tiles<<<(nt + 1023) / 1024, 1024, 0, h->stream>>>(h->tp, cnt1, cnt2, ovf, h->t_off, h->t_end, h->t_woff,
+                                                               h->t_oct, h->t_seg);
       k_reorder<T><<<fb_grid, 256, 0, h->stream>>>(h->g, pp, nbricks, R(h->psi), h->t_rank, h->t_off, ovf, R(h->sx),
                                                    R(h->sy), R(h->sz), h->sidx);
       HIPCHK(hipGetLastError());
@@ -689,20 +693,22 @@ struct Pipe {
           if (h->fix)
             k_scatter_tile81<T, 12, 20, true><<<grid, 256, tile_lds(h, 0, sizeof(double)), h->stream>>>(
                 h->g, sp, h->tp, reorder, R(h->sx), R(h->sy), R(h->sz), h->sidx, h->t_off, h->t_end, h->t_woff,
-                h->rho_fix, h->rho_part, h->t_cnt, 2 * h->tp.ntiles + 1, fix_scale);
+                h->t_oct, h->t_seg, h->rho_fix, h->rho_part, h->t_cnt,
+                (kOct + 1) * h->tp.ntiles + 1, fix_scale);
           else
             k_scatter_tile81<T, 12, 20, false><<<grid, 256, tile_lds(h, 0, sizeof(double)), h->stream>>>(
                 h->g, sp, h->tp, reorder, R(h->sx), R(h->sy), R(h->sz), h->sidx, h->t_off, h->t_end, h->t_woff,
-                R(h->rho), h->rho_part, h->t_cnt, 2 * h->tp.ntiles + 1, fix_scale);
+                h->t_oct, h->t_seg, R(h->rho), h->rho_part, h->t_cnt,
+                (kOct + 1) * h->tp.ntiles + 1, fix_scale);
           h->cnt_clean = true;
         } else if (h->fix) {
           k_scatter_tile<T, true><<<grid, 256, tile_lds(h, ncol, sizeof(double)), h->stream>>>(
               h->g, sp, h->tp, h->hull, ncol, reorder, R(h->sx), R(h->sy), R(h->sz), h->sidx, h->t_off, h->t_end,
-              h->t_woff, h->rho_fix, h->rho_part, fix_scale);
+              h->t_woff, h->t_oct, h->t_seg, h->rho_fix, h->rho_part, fix_scale);
         } else {
           k_scatter_tile<T, false><<<grid, 256, tile_lds(h, ncol, sizeof(double)), h->stream>>>(
               h->g, sp, h->tp, h->hull, ncol, reorder, R(h->sx), R(h->sy), R(h->sz), h->sidx, h->t_off, h->t_end,
-              h->t_woff, R(h->rho), h->rho_part, fix_scale);
+              h->t_woff, h->t_oct, h->t_seg, R(h->rho), h->rho_part, fix_scale);
         }
       } else if (h->c.mk == 3) {
         if (h->fix)
@@ -817,12 +823,12 @@ struct Pipe {
         const int grid = h->tp.ntiles + (int)(N / h->tp.chunk) + 1;
         if (h->std81)
           k_gather_tile81<T, 12, 20><<<grid, 256, tile_lds(h, 0, sizeof(T)), h->stream>>>(
-              h->g, hp, h->tp, h->last_rsd, R(h->sx), R(h->sy), R(h->sz), h->sidx, h->t_off, h->t_end, h->t_woff, R(h->plike),
-              R(h->V));
+              h->g, hp, h->tp, h->last_rsd, R(h->sx), R(h->sy), R(h->sz), h->sidx, h->t_off, h->t_end, h->t_woff,
+              h->t_oct, h->t_seg, R(h->plike), R(h->V));
         else
           k_gather_tile<T><<<grid, 256, tile_lds(h, hp.ncol, sizeof(T)), h->stream>>>(
-              h->g, hp, h->tp, h->last_rsd, R(h->sx), R(h->sy), R(h->sz), h->sidx, h->t_off, h->t_end, h->t_woff, R(h->plike),
-              R(h->V));
+              h->g, hp, h->tp, h->last_rsd, R(h->sx), R(h->sy), R(h->sz), h->sidx, h->t_off, h->t_end, h->t_woff,
+              h->t_oct, h->t_seg, R(h->plike), R(h->V));
       } else {
         k_gather_sph<T><<<nblk_full(N), 256, hp.ncol * sizeof(int4), h->stream>>>(h->g, make_pos(h, h->last_rsd), hp,
                                                                                   R(h->psi), R(h->plike), R(h->V));
@@ -1695,13 +1701,16 @@ int bchmc_create(const bchmc_config *cfg, bchmc_handle **out) {
           const long long mean_occ = (long long)tp.tx * tp.ty * tp.tz;
           long long cap = std::max<long long>(8 * mean_occ, 64);
           if (const char *ev = std::getenv("BCHMC_SORT_CAP")) cap = atoll(ev);
+          cap -= cap % kOct;  // eight octant segments per tile
           size_t nrec = N;
           h->sort_direct = cap > 0 && cap < (1ll << 30);  // record offsets are 64-bit, per-tile ranges 32-bit
           if (h->sort_direct) {
             tp.cap = (int)cap;
             nrec = std::max<size_t>(N, (size_t)cap * tp.ntiles);
           }
-          CHK(dev_alloc(h, &h->t_cnt, 2 * (size_t)tp.ntiles + 2));
+          CHK(dev_alloc(h, &h->t_cnt, (kOct + 1) * (size_t)tp.ntiles + 2));
+          CHK(dev_alloc(h, &h->t_oct, 2 * (size_t)tp.ntiles));
+          CHK(dev_alloc(h, &h->t_seg, (size_t)1));
           CHK(dev_alloc(h, &h->t_off, (size_t)tp.ntiles));
           CHK(dev_alloc(h, &h->t_end, (size_t)tp.ntiles));
           CHK(dev_alloc(h, &h->t_woff, (size_t)tp.ntiles + 1));
@@ -1733,7 +1742,7 @@ void bchmc_destroy(bchmc_handle *h) {
   void *ptrs[] = {h->work,  h->wS,       h->wM,    h->qk,    h->pk,   h->gk,     h->Ck,         h->tC,   h->psi,
                   h->V,     h->rho,      h->plike, h->ioq,   h->iop,  h->gprior, h->glike,      h->conv, h->convF,
                   h->dstage, h->rho_fix, h->cq, h->cp, h->qk2, h->pk2, h->xtw, h->part6, h->rho_part, h->partA, h->guard, h->stop, h->steps_done, h->hull,  h->t_cnt, h->t_off,
-                  h->t_woff, h->t_end, h->t_rank,  h->sx,    h->sy,    h->sz,   h->sidx};
+                  h->t_woff, h->t_oct, h->t_seg, h->t_end, h->t_rank,  h->sx,    h->sy,    h->sz,   h->sidx};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   for (int f = 0; f < 6; f++)

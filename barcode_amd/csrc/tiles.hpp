@@ -27,8 +27,21 @@ struct TilePar {
   int R;              // halo = farthest stencil offset
   int lx, ly, lz;     // LDS tile shape = t + 2R
   int chunk;          // max particles per work item
-  int cap;            // record slots reserved per tile by the one-pass binning (k_bin<DIRECT>)
+  int cap;            // record slots reserved per tile by the one-pass binning (k_bin<DIRECT>), a multiple of 8:
+                      // the tile's slots are eight segments of cap / 8, one per sub-cell octant of the particle
 };
+
+constexpr int kOct = 8;  // sub-cell octants: (x, y, z) in the upper half of the home cell -> bits 2, 1, 0
+
+// Sub-cell octant of a position: the 64 lanes of a wave should share most of the stencil cells that can pass the
+// `r/h <= 2` test, and a wave pays for every candidate ANY of its lanes needs (81 unsorted, ~51 within one octant).
+// Ordering only: results do not depend on it.
+template <typename T>
+__device__ __forceinline__ int subcell_octant(T x, T y, T z, T inv_d) {
+  const T fx = x * inv_d, fy = y * inv_d, fz = z * inv_d;
+  return ((fx - r_floor(fx) >= T(0.5)) ? 4 : 0) | ((fy - r_floor(fy) >= T(0.5)) ? 2 : 0) |
+         ((fz - r_floor(fz) >= T(0.5)) ? 1 : 0);
+}
 
 constexpr int kSortFlagNoScatter = 1 << 30;  // record flag: particle fails getDensity_SPH's domain test
 
@@ -91,27 +104,114 @@ __device__ __forceinline__ long long brick_particle(const Geo &g, int b, int &i,
   return p;
 }
 
-// Binning.  The workgroup first counts its particles per tile in an LDS hash table, then reserves one contiguous
-// rank range per distinct tile with a single global atomic (a handful per workgroup instead of one returning
-// atomic per particle on ~n^3/2048 hot counters).  Particles with a non-finite position are left out; the gather
-// gives them V = 0.
-//   DIRECT = true  (one-pass sort): every tile owns `tp.cap` record slots, the particle's record (position, index |
-//                  flag) goes straight to slot tile * cap + rank.  A rank >= cap raises *ovf and the record is dropped:
-//                  the two-pass kernels below then redo the sort from scratch (they return at once otherwise).
-//   DIRECT = false (two-pass fallback, pass 1): tile id and arrival rank of every particle to tile_rank.
-template <typename T, bool DIRECT>
+// Binning.  The workgroup first counts its particles per counter (tile, or tile and sub-cell octant) in an LDS hash
+// table, then reserves one contiguous rank range per distinct counter with a single global atomic (a handful per
+// workgroup instead of one returning atomic per particle on hot counters).  Particles with a non-finite position are
+// left out; the gather gives them V = 0.
+//
+// k_bin_direct (one-pass sort): every (tile, sub-cell octant) owns `tp.cap / 8` record slots, the particle's record
+//   (position, index | flag) goes straight to slot tile * cap + octant * cap / 8 + rank: the records of a tile come out
+//   ordered by octant, which is the order the scatter / gather kernels want (no sorting prologue in them).  A rank
+//   >= cap / 8 raises *ovf and the record is dropped: the two-pass kernels below then redo the sort from scratch (they
+//   return at once otherwise).  A workgroup bins kBinPer bricks (an 8 x 8 x 16 block of the Lagrangian lattice) through
+//   one hash table: eight counters per tile mean eight times the global atomics per brick, four bricks per table bring
+//   them back to about twice the per-tile number (k_bin_direct with one brick per table: 0.32 ms at 256^3, the per-tile
+//   binning it replaced: 0.25 ms).
+// k_bin (two-pass fallback, pass 1): tile id and arrival rank of every particle to tile_rank.
+constexpr int kBinPer = 4;
+
+// brick m (0..3) of super-brick sb: a 2 x 2 group in (i, j) when the bricks are 4 x 4 x 16, else four consecutive ones
+__device__ __forceinline__ int super_brick(const Geo &g, int sb, int m) {
+  const int n = g.n;
+  if ((n & 15) == 0) {
+    const int nbz = n >> 4, nby = n >> 2, nby2 = nby >> 1;
+    const int sbk = sb % nbz, sbj = (sb / nbz) % nby2, sbi = sb / (nbz * nby2);
+    return sbk + nbz * ((2 * sbj + (m & 1)) + nby * (2 * sbi + (m >> 1)));
+  }
+  return sb * kBinPer + m;  // may run past the last brick: brick_particle then returns p >= N
+}
+
+template <typename T>
 __global__ void __launch_bounds__(256)
-k_bin(Geo g, PosPar pp, SphPar sp, TilePar tp, int nbricks, const T *__restrict__ psi, int *__restrict__ cnt,
-      int *__restrict__ ovf,
-      int2 *__restrict__ tile_rank, T *__restrict__ sx, T *__restrict__ sy, T *__restrict__ sz, int *__restrict__ sidx,
-      T *__restrict__ V, double *__restrict__ zero_part) {
-  constexpr int kSlots = 512;
+k_bin_direct(Geo g, PosPar pp, SphPar sp, TilePar tp, int nsuper, const T *__restrict__ psi, int *__restrict__ cnt,
+             int *__restrict__ ovf, T *__restrict__ sx, T *__restrict__ sy, T *__restrict__ sz, int *__restrict__ sidx,
+             T *__restrict__ V, double *__restrict__ zero_part) {
+  constexpr int kSlots = 2048;  // > kBinPer * 256 distinct counters can never occur: the probing always terminates
   __shared__ int hkey[kSlots], hcnt[kSlots], hbase[kSlots];
   // the scatter that follows accumulates sum(rho) into these partials: cleared here instead of by a fill launch
-  if (DIRECT && zero_part && blockIdx.x == 0)
+  if (zero_part && blockIdx.x == 0)
     for (int i = threadIdx.x; i < kRedBlocks; i += blockDim.x) zero_part[i] = 0.;
-  if (!DIRECT && !*ovf) return;
-  // DIRECT: one brick per workgroup; fallback: a small grid strides over the bricks (it usually returns above)
+  const HomeCell<T> hc = make_home<T>(g);
+  for (int sb = blockIdx.x; sb < nsuper; sb += gridDim.x) {
+    for (int s = threadIdx.x; s < kSlots; s += blockDim.x) {
+      hkey[s] = 0;
+      hcnt[s] = 0;
+    }
+    __syncthreads();
+    long long p[kBinPer];
+    int key[kBinPer], slot[kBinPer], local[kBinPer], flag[kBinPer];
+    T x[kBinPer], y[kBinPer], z[kBinPer];
+#pragma unroll
+    for (int m = 0; m < kBinPer; m++) {
+      int i, j, k;
+      p[m] = brick_particle(g, super_brick(g, sb, m), i, j, k);
+      key[m] = -1;
+      slot[m] = local[m] = flag[m] = 0;
+      x[m] = y[m] = z[m] = T(0);
+      if (p[m] >= g.N) continue;
+      particle_pos<T>(pp, i, j, k, psi[p[m]], psi[p[m] + g.N], psi[p[m] + 2 * g.N], x[m], y[m], z[m]);
+      if (pos_ok(g, x[m], y[m], z[m])) {
+        const int t = tile_of_wrapped(tp, wrap_cell(home_cell_i(hc, x[m]), g.n), wrap_cell(home_cell_i(hc, y[m]), g.n),
+                                      wrap_cell(home_cell_i(hc, z[m]), g.n));
+        flag[m] = in_domain(g, sp, x[m], y[m], z[m]) ? 0 : kSortFlagNoScatter;
+        key[m] = t * kOct + subcell_octant<T>(x[m], y[m], z[m], hc.inv_d);
+        int sl = (int)(((unsigned)key[m] * 2654435761u) >> 21) & (kSlots - 1);
+        for (;;) {
+          const int old = atomicCAS(&hkey[sl], 0, key[m] + 1);
+          if (old == 0 || old == key[m] + 1) break;
+          sl = (sl + 1) & (kSlots - 1);
+        }
+        slot[m] = sl;
+        local[m] = atomicAdd(&hcnt[sl], 1);
+      } else {
+        V[p[m]] = T(0);
+        V[p[m] + g.N] = T(0);
+        V[p[m] + 2 * g.N] = T(0);
+      }
+    }
+    __syncthreads();
+    for (int s = threadIdx.x; s < kSlots; s += blockDim.x)
+      if (hkey[s]) hbase[s] = atomicAdd(&cnt[hkey[s] - 1], hcnt[s]);
+    __syncthreads();
+    const int seg = tp.cap / kOct;
+#pragma unroll
+    for (int m = 0; m < kBinPer; m++) {
+      if (key[m] < 0) continue;
+      const int rank = hbase[slot[m]] + local[m];
+      if (rank >= seg) {
+        ovf[0] = 1;  // benign race: every writer stores 1
+        ovf[1] = 1;  // sticky copy: the host enlarges the slots before the next trajectory
+      } else {
+        const int t = key[m] / kOct;
+        const long long dst = (long long)t * tp.cap + (long long)(key[m] - t * kOct) * seg + rank;
+        sx[dst] = x[m];
+        sy[dst] = y[m];
+        sz[dst] = z[m];
+        sidx[dst] = (int)p[m] | flag[m];
+      }
+    }
+    __syncthreads();  // the hash table is reused by the next super-brick
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_bin(Geo g, PosPar pp, SphPar sp, TilePar tp, int nbricks, const T *__restrict__ psi, int *__restrict__ cnt,
+      const int *__restrict__ ovf, int2 *__restrict__ tile_rank, T *__restrict__ V) {
+  constexpr int kSlots = 512;
+  __shared__ int hkey[kSlots], hcnt[kSlots], hbase[kSlots];
+  if (!*ovf) return;  // the one-pass binning succeeded
+  // a small grid strides over the bricks (it usually returns above)
   for (int brick = blockIdx.x; brick < nbricks; brick += gridDim.x) {
     for (int s = threadIdx.x; s < kSlots; s += blockDim.x) {
       hkey[s] = 0;
@@ -122,8 +222,8 @@ k_bin(Geo g, PosPar pp, SphPar sp, TilePar tp, int nbricks, const T *__restrict_
     const long long p = brick_particle(g, brick, i, j, k);
     const bool live = p < g.N;
     int t = -1, slot = 0, local = 0, flag = 0;
-    T x = T(0), y = T(0), z = T(0);
     if (live) {
+      T x, y, z;
       particle_pos<T>(pp, i, j, k, psi[p], psi[p + g.N], psi[p + 2 * g.N], x, y, z);
       if (pos_ok(g, x, y, z)) {
         const HomeCell<T> hc = make_home<T>(g);
@@ -147,23 +247,7 @@ k_bin(Geo g, PosPar pp, SphPar sp, TilePar tp, int nbricks, const T *__restrict_
     for (int s = threadIdx.x; s < kSlots; s += blockDim.x)
       if (hkey[s]) hbase[s] = atomicAdd(&cnt[hkey[s] - 1], hcnt[s]);
     __syncthreads();
-    if (live && DIRECT) {
-      if (t >= 0) {
-        const int rank = hbase[slot] + local;
-        if (rank >= tp.cap) {
-          ovf[0] = 1;  // benign race: every writer stores 1
-          ovf[1] = 1;  // sticky copy: the host enlarges the slots before the next trajectory
-        } else {
-          const long long dst = (long long)t * tp.cap + rank;
-          sx[dst] = x;
-          sy[dst] = y;
-          sz[dst] = z;
-          sidx[dst] = (int)p | flag;
-        }
-      }
-    } else if (live) {
-      tile_rank[p] = (t < 0) ? make_int2(-1, 0) : make_int2(t, (hbase[slot] + local) | flag);
-    }
+    if (live) tile_rank[p] = (t < 0) ? make_int2(-1, 0) : make_int2(t, (hbase[slot] + local) | flag);
     __syncthreads();  // the hash table is reused by the next brick
   }
 }
@@ -204,25 +288,35 @@ __device__ __forceinline__ int2 block_exclusive_scan2_1024(int a, int b, int2 *w
   return make_int2(base.x + ia - a, base.y + ib - b);
 }
 
+// cnt_direct holds 8 counters per tile (one per octant); `oct` receives, per tile, the exclusive prefix of those eight
+// (logical record index where each octant's segment starts) -- all zero after a fallback sort (records contiguous).
 __global__ void __launch_bounds__(1024)
 k_scan_tiles(TilePar tp, const int *__restrict__ cnt_direct, const int *__restrict__ cnt_fallback,
              const int *__restrict__ ovf, long long *__restrict__ off, long long *__restrict__ tend,
-             int *__restrict__ woff) {
+             int *__restrict__ woff, int4 *__restrict__ oct, int *__restrict__ seg_out) {
   // One tile per thread, ceil(ntiles / 1024) workgroups.  A workgroup first sums the counts of all tiles before its
   // own range (coalesced reads, at most 4 * ntiles bytes), then scans its 1024 tiles: every load and store is
   // coalesced, which a single workgroup striding over all tiles was not (33 us for 16384 tiles).
   __shared__ int2 wtot[16];
   __shared__ int2 s_base;
   const bool direct = !*ovf;
-  const int *cnt = direct ? cnt_direct : cnt_fallback;
   const int T = tp.ntiles, tid = threadIdx.x;
+  // record layout of this sort for the tile kernels (they must not read *ovf: the scatter clears it for the next
+  // force evaluation while the gather still needs the layout): slots per octant segment, 0 = contiguous records
+  if (blockIdx.x == 0 && tid == 0) *seg_out = direct ? tp.cap / kOct : 0;
+  const int4 *cnt8 = reinterpret_cast<const int4 *>(cnt_direct);
+  auto count_of = [&](int t) {
+    if (!direct) return cnt_fallback[t];
+    const int4 a = cnt8[2 * t], b = cnt8[2 * t + 1];
+    return (a.x + a.y) + (a.z + a.w) + (b.x + b.y) + (b.z + b.w);
+  };
   // chunk is a power of two unless overridden for experiments: shift instead of a runtime division per tile
   const int sh = (tp.chunk & (tp.chunk - 1)) == 0 ? __ffs(tp.chunk) - 1 : -1;
   auto items = [&](int c) { return sh >= 0 ? (c + tp.chunk - 1) >> sh : (c + tp.chunk - 1) / tp.chunk; };
   const int first = blockIdx.x * 1024;
   int pa = 0, pb = 0;
   for (int t = tid; t < first; t += 1024) {
-    const int c = cnt[t];
+    const int c = count_of(t);
     pa += c;
     pb += items(c);
   }
@@ -232,7 +326,7 @@ k_scan_tiles(TilePar tp, const int *__restrict__ cnt_direct, const int *__restri
   __syncthreads();
   const int2 base = s_base;
   const int t = first + tid;
-  const int c = t < T ? cnt[t] : 0;
+  const int c = t < T ? count_of(t) : 0;
   const int2 ex = block_exclusive_scan2_1024(c, items(c), wtot);
   const int ea = base.x + ex.x, eb = base.y + ex.y;
   if (t < T) {
@@ -241,6 +335,15 @@ k_scan_tiles(TilePar tp, const int *__restrict__ cnt_direct, const int *__restri
     tend[t] = o + c;
     woff[t] = eb;
     if (t == T - 1) woff[T] = eb + items(c);
+    int4 lo = make_int4(0, 0, 0, 0), hi = make_int4(0, 0, 0, 0);
+    if (direct) {
+      const int4 a = cnt8[2 * t], b = cnt8[2 * t + 1];
+      lo = make_int4(0, a.x, a.x + a.y, a.x + a.y + a.z);
+      const int h0 = lo.w + a.w;
+      hi = make_int4(h0, h0 + b.x, h0 + b.x + b.y, h0 + b.x + b.y + b.z);
+    }
+    oct[2 * t] = lo;
+    oct[2 * t + 1] = hi;
   }
 }
 
@@ -267,13 +370,34 @@ k_reorder(Geo g, PosPar pp, int nbricks, const T *__restrict__ psi, const int2 *
   }
 }
 
+// Logical record index of a tile -> slot relative to the tile's first slot.  After the one-pass binning the records
+// sit in eight octant segments of `seg` slots; P[o] = logical index of the first record of octant o.  After a
+// fallback sort they are contiguous (seg = 0: identity).
+struct OctMap {
+  int seg;
+  int P[kOct];
+  __device__ __forceinline__ int slot(int s) const {
+    if (seg == 0) return s;
+    int o = 0, p0 = 0;
+#pragma unroll
+    for (int m = 1; m < kOct; m++)
+      if (s >= P[m]) {
+        o = m;
+        p0 = P[m];
+      }
+    return o * seg + (s - p0);
+  }
+};
+
 // Work item -> (tile, particle range).  Returns false when this workgroup has nothing to do.
 __device__ __forceinline__ bool tile_work(const TilePar &tp, const long long *__restrict__ off,
-                                          const long long *__restrict__ tend, const int *__restrict__ woff, int &tile,
-                                          long long &base, int &p_begin, int &p_end) {
+                                          const long long *__restrict__ tend, const int *__restrict__ woff,
+                                          const int4 *__restrict__ oct, const int *__restrict__ seg_in, int &tile,
+                                          long long &base, int &p_begin, int &p_end, OctMap &om) {
   // base = first record slot of the tile (64-bit: ntiles * cap may exceed 2^31), [p_begin, p_end) relative to it
   __shared__ int s_tile, s_b, s_e;
   __shared__ long long s_base;
+  __shared__ int s_oct[kOct + 1];
   if (threadIdx.x == 0) {
     const int w = blockIdx.x;
     int t = -1, b = 0, e = 0;
@@ -293,12 +417,22 @@ __device__ __forceinline__ bool tile_work(const TilePar &tp, const long long *__
     s_b = b;
     s_e = e;
     s_base = o;
+    s_oct[kOct] = *seg_in;  // written by k_scan_tiles for this sort
+    if (t >= 0) {
+      const int4 lo = oct[2 * t], hi = oct[2 * t + 1];
+      s_oct[0] = lo.x; s_oct[1] = lo.y; s_oct[2] = lo.z; s_oct[3] = lo.w;
+      s_oct[4] = hi.x; s_oct[5] = hi.y; s_oct[6] = hi.z; s_oct[7] = hi.w;
+    }
   }
   __syncthreads();
   tile = s_tile;
   p_begin = s_b;
   p_end = s_e;
   base = s_base;
+  // uniform over the workgroup: keep the map in scalar registers
+  om.seg = __builtin_amdgcn_readfirstlane(s_oct[kOct]);
+#pragma unroll
+  for (int m = 0; m < kOct; m++) om.P[m] = __builtin_amdgcn_readfirstlane(s_oct[m]);
   return tile >= 0;
 }
 
@@ -374,6 +508,7 @@ template <typename T, bool FIX>
 __global__ void __launch_bounds__(256)
 k_scatter_tile(Geo g, SphPar sp, TilePar tp, const int4 *__restrict__ cols, int ncol, int reorder, T *sx, T *sy, T *sz,
                int *sidx, const long long *__restrict__ off, const long long *__restrict__ tend, const int *__restrict__ woff,
+               const int4 *__restrict__ oct, const int *__restrict__ seg_in,
                typename Cell<FIX, T>::type *__restrict__ rho, double *__restrict__ rho_part, double fix_scale) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw_scatter[];
   // accumulate in double also for float fields (fixed point in deterministic mode)
@@ -381,7 +516,8 @@ k_scatter_tile(Geo g, SphPar sp, TilePar tp, const int4 *__restrict__ cols, int 
   Acc *s_tile_acc = reinterpret_cast<Acc *>(s_raw_scatter);
   int tile, pb, pe;
   long long rec0;
-  if (!tile_work(tp, off, tend, woff, tile, rec0, pb, pe)) return;
+  OctMap om;
+  if (!tile_work(tp, off, tend, woff, oct, seg_in, tile, rec0, pb, pe, om)) return;
   sx += rec0;  // this tile's record slots; pb, pe are relative to them
   sy += rec0;
   sz += rec0;
@@ -392,15 +528,17 @@ k_scatter_tile(Geo g, SphPar sp, TilePar tp, const int4 *__restrict__ cols, int 
   for (int c = threadIdx.x; c < ncell; c += blockDim.x) s_tile_acc[c] = Acc(0);
   const T d = (T)g.d;
   const HomeCell<T> hc = make_home<T>(g);
-  if (reorder) subsort_subcell<T>(reorder, pb, pe, hc.inv_d, sx, sy, sz, sidx);
+  // the one-pass binning delivers the records ordered by octant; after a fallback sort they are ordered here
+  if (reorder && om.seg == 0) subsort_subcell<T>(reorder, pb, pe, hc.inv_d, sx, sy, sz, sidx);
   __syncthreads();
   const int tzi = tile % tp.ntz, tyi = (tile / tp.ntz) % tp.nty, txi = tile / (tp.ntz * tp.nty);
   const int ox = txi * tp.tx - tp.R, oy = tyi * tp.ty - tp.R, oz = tzi * tp.tz - tp.R;  // global cell of LDS (0,0,0)
   const int n = g.n, R = sp.reach;
   const T r2_lim = (T)sp.r2_lim, h_inv = (T)sp.h_inv, w_norm = (T)sp.w_norm;
   for (int s = pb + threadIdx.x; s < pe; s += blockDim.x) {
-    if (sidx[s] & kSortFlagNoScatter) continue;
-    const T x = sx[s], y = sy[s], z = sz[s];
+    const int r = om.slot(s);
+    if (sidx[r] & kSortFlagNoScatter) continue;
+    const T x = sx[r], y = sy[r], z = sz[r];
     const int ix = home_cell_i(hc, x), iy = home_cell_i(hc, y), iz = home_cell_i(hc, z);
     const T ccx = ((T)ix + T(0.5)) * d, ccy = ((T)iy + T(0.5)) * d, ccz = ((T)iz + T(0.5)) * d;
     const int hx = wrap_cell(ix, n) - ox, hy = wrap_cell(iy, n) - oy, hz = wrap_cell(iz, n) - oz;  // home cell in LDS coords
@@ -468,13 +606,14 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 k_gather_tile(Geo g, HullPar hp, TilePar tp, int rsd, const T *__restrict__ sx, const T *__restrict__ sy,
               const T *__restrict__ sz, const int *__restrict__ sidx, const long long *__restrict__ off,
-              const long long *__restrict__ tend, const int *__restrict__ woff, const T *__restrict__ plike,
-              T *__restrict__ V) {
+              const long long *__restrict__ tend, const int *__restrict__ woff, const int4 *__restrict__ oct,
+              const int *__restrict__ seg_in, const T *__restrict__ plike, T *__restrict__ V) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw_gather[];
   T *s_tile_pl = reinterpret_cast<T *>(s_raw_gather);
   int tile, pb, pe;
   long long rec0;
-  if (!tile_work(tp, off, tend, woff, tile, rec0, pb, pe)) return;
+  OctMap om;
+  if (!tile_work(tp, off, tend, woff, oct, seg_in, tile, rec0, pb, pe, om)) return;
   sx += rec0;  // this tile's record slots; pb, pe are relative to them
   sy += rec0;
   sz += rec0;
@@ -494,7 +633,8 @@ k_gather_tile(Geo g, HullPar hp, TilePar tp, int rsd, const T *__restrict__ sx, 
   const T d_h = (T)hp.d_h, h_inv = (T)hp.h_inv, norm = (T)hp.norm;
   const HomeCell<T> hc = make_home<T>(g);
   for (int s = pb + threadIdx.x; s < pe; s += blockDim.x) {
-    const T px = sx[s], py = sy[s], pz = sz[s];
+    const int r = om.slot(s);
+    const T px = sx[r], py = sy[r], pz = sz[r];
     const int ix = home_cell_i(hc, px), iy = home_cell_i(hc, py), iz = home_cell_i(hc, pz);
     const T dpcx = px * h_inv - ((T)ix + T(0.5)) * d_h;
     const T dpcy = py * h_inv - ((T)iy + T(0.5)) * d_h;
@@ -527,7 +667,7 @@ k_gather_tile(Geo g, HullPar hp, TilePar tp, int rsd, const T *__restrict__ sx, 
     vy *= normalize;
     vz *= normalize;
     if (rsd) vz += (T)hp.f1 * vz;
-    const long long p = sidx[s] & ~kSortFlagNoScatter;
+    const long long p = sidx[r] & ~kSortFlagNoScatter;
     V[p] = vx;
     V[p + g.N] = vy;
     V[p + 2 * g.N] = vz;
@@ -562,20 +702,23 @@ template <typename T, int LY, int LZ, bool FIX>
 __global__ void __launch_bounds__(256, BCHMC_SCATTER_WAVES)
 k_scatter_tile81(Geo g, SphPar sp, TilePar tp, int reorder, T *sx, T *sy, T *sz, int *sidx,
                  const long long *__restrict__ off, const long long *__restrict__ tend, const int *__restrict__ woff,
+                 const int4 *__restrict__ oct, const int *__restrict__ seg_in,
                  typename Cell<FIX, T>::type *__restrict__ rho, double *__restrict__ rho_part, int *__restrict__ cnt_zero,
                  int ncnt_zero, double fix_scale) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw_scatter81[];
   using Acc = typename Cell<FIX, double>::type;
   Acc *s_tile_acc = reinterpret_cast<Acc *>(s_raw_scatter81);
-  // The binning counters (and its overflow flag) have been consumed by k_scan_tiles / k_reorder: clear them for the
-  // next force evaluation's k_bin here, two per workgroup, instead of with a fill launch (grid >= ntiles + 1).
-  if (threadIdx.x < 2) {
-    const int i = 2 * (int)blockIdx.x + (int)threadIdx.x;
+  // The binning counters (8 + 1 per tile, and the overflow flag) have been consumed by k_scan_tiles / k_reorder:
+  // clear them for the next force evaluation's k_bin here, nine per workgroup, instead of with a fill launch
+  // (grid >= ntiles + 1).
+  if (threadIdx.x < kOct + 1) {
+    const int i = (kOct + 1) * (int)blockIdx.x + (int)threadIdx.x;
     if (i < ncnt_zero) cnt_zero[i] = 0;
   }
   int tile, pb, pe;
   long long rec0;
-  if (!tile_work(tp, off, tend, woff, tile, rec0, pb, pe)) return;
+  OctMap om;
+  if (!tile_work(tp, off, tend, woff, oct, seg_in, tile, rec0, pb, pe, om)) return;
   sx += rec0;  // this tile's record slots; pb, pe are relative to them
   sy += rec0;
   sz += rec0;
@@ -584,7 +727,8 @@ k_scatter_tile81(Geo g, SphPar sp, TilePar tp, int reorder, T *sx, T *sy, T *sz,
   for (int c = threadIdx.x; c < ncell; c += blockDim.x) s_tile_acc[c] = Acc(0);
   const T d = (T)g.d;
   const HomeCell<T> hc = make_home<T>(g);
-  if (reorder) subsort_subcell<T>(reorder, pb, pe, hc.inv_d, sx, sy, sz, sidx);
+  // the one-pass binning delivers the records ordered by octant; after a fallback sort they are ordered here
+  if (reorder && om.seg == 0) subsort_subcell<T>(reorder, pb, pe, hc.inv_d, sx, sy, sz, sidx);
   __syncthreads();
   const int tzi = tile % tp.ntz, tyi = (tile / tp.ntz) % tp.nty, txi = tile / (tp.ntz * tp.nty);
   const int ox = txi * tp.tx - 2, oy = tyi * tp.ty - 2, oz = tzi * tp.tz - 2;  // global cell of LDS (0,0,0)
@@ -595,8 +739,9 @@ k_scatter_tile81(Geo g, SphPar sp, TilePar tp, int reorder, T *sx, T *sy, T *sz,
   const T q2_lim = (T)(sp.r2_lim * sp.h_inv * sp.h_inv);
   const T c34w = T(0.75) * w_norm, c32w = T(-1.5) * w_norm, c14w = T(0.25) * w_norm;
   for (int s = pb + threadIdx.x; s < pe; s += blockDim.x) {
-    if (sidx[s] & kSortFlagNoScatter) continue;
-    const T x = sx[s], y = sy[s], z = sz[s];
+    const int r = om.slot(s);
+    if (sidx[r] & kSortFlagNoScatter) continue;
+    const T x = sx[r], y = sy[r], z = sz[r];
     const int ix = home_cell_i(hc, x), iy = home_cell_i(hc, y), iz = home_cell_i(hc, z);
     const T ccx = ((T)ix + T(0.5)) * d, ccy = ((T)iy + T(0.5)) * d, ccz = ((T)iz + T(0.5)) * d;
     const int hx = wrap_cell(ix, n) - ox, hy = wrap_cell(iy, n) - oy, hz = wrap_cell(iz, n) - oz;  // home cell in LDS coords
@@ -661,13 +806,14 @@ template <typename T, int LY, int LZ>
 __global__ void __launch_bounds__(256, BCHMC_GATHER_WAVES)
 k_gather_tile81(Geo g, HullPar hp, TilePar tp, int rsd, const T *__restrict__ sx, const T *__restrict__ sy,
                 const T *__restrict__ sz, const int *__restrict__ sidx, const long long *__restrict__ off,
-                const long long *__restrict__ tend, const int *__restrict__ woff, const T *__restrict__ plike,
-                T *__restrict__ V) {
+                const long long *__restrict__ tend, const int *__restrict__ woff, const int4 *__restrict__ oct,
+                const int *__restrict__ seg_in, const T *__restrict__ plike, T *__restrict__ V) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw_gather81[];
   T *s_tile_pl = reinterpret_cast<T *>(s_raw_gather81);
   int tile, pb, pe;
   long long rec0;
-  if (!tile_work(tp, off, tend, woff, tile, rec0, pb, pe)) return;
+  OctMap om;
+  if (!tile_work(tp, off, tend, woff, oct, seg_in, tile, rec0, pb, pe, om)) return;
   sx += rec0;  // this tile's record slots; pb, pe are relative to them
   sy += rec0;
   sz += rec0;
@@ -685,7 +831,8 @@ k_gather_tile81(Geo g, HullPar hp, TilePar tp, int rsd, const T *__restrict__ sx
   const T d_h = (T)hp.d_h, h_inv = (T)hp.h_inv, norm = (T)hp.norm;
   const HomeCell<T> hc = make_home<T>(g);
   for (int s = pb + threadIdx.x; s < pe; s += blockDim.x) {
-    const T px = sx[s], py = sy[s], pz = sz[s];
+    const int r = om.slot(s);
+    const T px = sx[r], py = sy[r], pz = sz[r];
     const int ix = home_cell_i(hc, px), iy = home_cell_i(hc, py), iz = home_cell_i(hc, pz);
     const T dpcx = px * h_inv - ((T)ix + T(0.5)) * d_h;
     const T dpcy = py * h_inv - ((T)iy + T(0.5)) * d_h;
@@ -746,7 +893,7 @@ k_gather_tile81(Geo g, HullPar hp, TilePar tp, int rsd, const T *__restrict__ sx
     vy *= normalize;
     vz *= normalize;
     if (rsd) vz += (T)hp.f1 * vz;
-    const long long p = sidx[s] & ~kSortFlagNoScatter;
+    const long long p = sidx[r] & ~kSortFlagNoScatter;
     V[p] = vx;
     V[p + g.N] = vy;
     V[p + 2 * g.N] = vz;
