@@ -84,6 +84,8 @@ struct bchmc_handle {
   int *stop = nullptr;
   unsigned long long *steps_done = nullptr;
   double *h_part = nullptr;                          // pinned host staging for partials
+  double *spec_bins = nullptr;                       // measure_spectrum's 3 * n_bin accumulators
+  size_t spec_cap = 0;
   // delta_Hamiltonian of the last bchmc_leapfrog, answered without transfers when asked about the same host arrays
   struct {
     bool valid = false;
@@ -121,9 +123,9 @@ struct bchmc_handle {
   int *t_seg = nullptr;                      // 1: slots per octant segment of the current sort, 0 = contiguous records
   long long *t_off = nullptr, *t_end = nullptr;  // ntiles each: record range of every tile (ntiles * cap can pass 2^31)
   int2 *t_rank = nullptr;                                      // N
-  void *sx = nullptr, *sy = nullptr, *sz = nullptr;            // N each: sorted positions
-  int *sidx = nullptr;                                         // N: original index | flags
+  void *srec = nullptr;  // tile-sorted particle records { x, y, z, original index | flags }: 4 * sizeof(T) bytes each
   bool sorted_valid = false;
+  bool ovf_seen = false;    // a tile overflowed its record slots since the slots were last sized (read back with steps_done)
   bool cnt_clean = false;   // t_cnt[0 .. 2 ntiles] was cleared by the last k_scatter_tile81 (no fill launch needed)
   bool have_eval = false;  // rho / psi hold a forward evaluation
   int last_rsd = 0;
@@ -358,14 +360,27 @@ int check_inputs(bchmc_handle *h) {
 
 // One-pass tile binning: if a tile overflowed its record slots since the last check (sticky flag set by
 // k_bin<DIRECT>; that step fell back to the two-pass sort), double the slots -- or give the one-pass path up when
-// they would no longer be addressable / allocatable.  Called at the start of every trajectory and forward model.
-int grow_sort_slots(bchmc_handle *h) {
-  if (!h->tiled || !h->sort_direct) return BCHMC_OK;
-  int *sticky = h->t_cnt + (kOct + 1) * (size_t)h->tp.ntiles + 1;
+// they would no longer be addressable / allocatable.  Called at the start of every trajectory and forward model; the
+// flag itself travels with the read-backs that synchronise anyway (read_ctl below: steps_done, bchmc_sync), so the
+// common case costs nothing here.
+int read_ctl(bchmc_handle *h, unsigned long long *steps_done) {
+  unsigned long long sd = 0;
   int seen = 0;
-  HIPCHK(hipMemcpyAsync(&seen, sticky, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  if (steps_done) HIPCHK(hipMemcpyAsync(&sd, h->steps_done, sizeof sd, hipMemcpyDeviceToHost, h->stream));
+  if (h->tiled && h->sort_direct)
+    HIPCHK(hipMemcpyAsync(&seen, h->t_cnt + (kOct + 1) * (size_t)h->tp.ntiles + 1, sizeof(int), hipMemcpyDeviceToHost,
+                          h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
-  if (!seen) return BCHMC_OK;
+  if (steps_done) *steps_done = sd;
+  if (seen) h->ovf_seen = true;
+  return BCHMC_OK;
+}
+
+int grow_sort_slots(bchmc_handle *h) {
+  if (!h->tiled || !h->sort_direct || !h->ovf_seen) return BCHMC_OK;
+  h->ovf_seen = false;
+  int *sticky = h->t_cnt + (kOct + 1) * (size_t)h->tp.ntiles + 1;
+  HIPCHK(hipStreamSynchronize(h->stream));  // rare path: the record slots are about to be replaced
   HIPCHK(hipMemsetAsync(sticky, 0, sizeof(int), h->stream));
   const long long cap = 2ll * h->tp.cap;
   h->sorted_valid = false;
@@ -377,21 +392,14 @@ int grow_sort_slots(bchmc_handle *h) {
   }
   // never fewer than N records: the two-pass sort packs all particles
   const size_t nrec = std::max<size_t>((size_t)h->g.N, (size_t)cap * h->tp.ntiles);
-  void *nx = nullptr, *ny = nullptr, *nz = nullptr, *ni = nullptr;
-  const bool ok = hipMalloc(&nx, nrec * h->esz) == hipSuccess && hipMalloc(&ny, nrec * h->esz) == hipSuccess &&
-                  hipMalloc(&nz, nrec * h->esz) == hipSuccess && hipMalloc(&ni, nrec * sizeof(int)) == hipSuccess;
-  if (!ok) {
-    for (void *p : {nx, ny, nz, ni})
-      if (p) (void)hipFree(p);
+  void *nrecs = nullptr;
+  if (hipMalloc(&nrecs, nrec * 4 * h->esz) != hipSuccess) {
     (void)hipGetLastError();
-    h->sort_direct = false;  // the existing arrays hold >= N records: enough for the two-pass sort
+    h->sort_direct = false;  // the existing array holds >= N records: enough for the two-pass sort
     return BCHMC_OK;
   }
-  for (void *p : {h->sx, h->sy, h->sz, (void *)h->sidx}) (void)hipFree(p);
-  h->sx = nx;
-  h->sy = ny;
-  h->sz = nz;
-  h->sidx = (int *)ni;
+  (void)hipFree(h->srec);
+  h->srec = nrecs;
   h->tp.cap = (int)cap;
   return BCHMC_OK;
 }
@@ -657,16 +665,16 @@ struct Pipe {
       const int fb_grid = h->sort_direct ? std::min(nbricks, 512) : nbricks;
       if (h->sort_direct) {
         const int nsuper = (nbricks + kBinPer - 1) / kBinPer;
-        k_bin_direct<T><<<nsuper, 256, 0, h->stream>>>(h->g, pp, sp, h->tp, nsuper, R(h->psi), cnt1, ovf, R(h->sx),
-                                                       R(h->sy), R(h->sz), h->sidx, R(h->V), h->rho_part);
+        k_bin_direct<T><<<nsuper, 256, 0, h->stream>>>(h->g, pp, sp, h->tp, nsuper, R(h->psi), cnt1, ovf,
+                                                       (RecQuad *)h->srec, R(h->V), h->rho_part);
       } else {
         HIPCHK(hipMemsetAsync(ovf, 1, 1, h->stream));  // non-zero flag: two-pass sort only
       }
       k_bin<T><<<fb_grid, 256, 0, h->stream>>>(h->g, pp, sp, h->tp, nbricks, R(h->psi), cnt2, ovf, h->t_rank, R(h->V));
       k_scan_tiles<<<(nt + 1023) / 1024, 1024, 0, h->stream>>>(h->tp, cnt1, cnt2, ovf, h->t_off, h->t_end, h->t_woff,
                                                                h->t_oct, h->t_seg);
-      k_reorder<T><<<fb_grid, 256, 0, h->stream>>>(h->g, pp, nbricks, R(h->psi), h->t_rank, h->t_off, ovf, R(h->sx),
-                                                   R(h->sy), R(h->sz), h->sidx);
+      k_reorder<T><<<fb_grid, 256, 0, h->stream>>>(h->g, pp, nbricks, R(h->psi), h->t_rank, h->t_off, ovf,
+                                                   (RecQuad *)h->srec);
       HIPCHK(hipGetLastError());
       h->sorted_valid = true;
     }
@@ -692,22 +700,22 @@ struct Pipe {
         if (h->std81) {
           if (h->fix)
             k_scatter_tile81<T, 12, 20, true><<<grid, 256, tile_lds(h, 0, sizeof(double)), h->stream>>>(
-                h->g, sp, h->tp, reorder, R(h->sx), R(h->sy), R(h->sz), h->sidx, h->t_off, h->t_end, h->t_woff,
+                h->g, sp, h->tp, reorder, (RecQuad *)h->srec, h->t_off, h->t_end, h->t_woff,
                 h->t_oct, h->t_seg, h->rho_fix, h->rho_part, h->t_cnt,
                 (kOct + 1) * h->tp.ntiles + 1, fix_scale);
           else
             k_scatter_tile81<T, 12, 20, false><<<grid, 256, tile_lds(h, 0, sizeof(double)), h->stream>>>(
-                h->g, sp, h->tp, reorder, R(h->sx), R(h->sy), R(h->sz), h->sidx, h->t_off, h->t_end, h->t_woff,
+                h->g, sp, h->tp, reorder, (RecQuad *)h->srec, h->t_off, h->t_end, h->t_woff,
                 h->t_oct, h->t_seg, R(h->rho), h->rho_part, h->t_cnt,
                 (kOct + 1) * h->tp.ntiles + 1, fix_scale);
           h->cnt_clean = true;
         } else if (h->fix) {
           k_scatter_tile<T, true><<<grid, 256, tile_lds(h, ncol, sizeof(double)), h->stream>>>(
-              h->g, sp, h->tp, h->hull, ncol, reorder, R(h->sx), R(h->sy), R(h->sz), h->sidx, h->t_off, h->t_end,
+              h->g, sp, h->tp, h->hull, ncol, reorder, (RecQuad *)h->srec, h->t_off, h->t_end,
               h->t_woff, h->t_oct, h->t_seg, h->rho_fix, h->rho_part, fix_scale);
         } else {
           k_scatter_tile<T, false><<<grid, 256, tile_lds(h, ncol, sizeof(double)), h->stream>>>(
-              h->g, sp, h->tp, h->hull, ncol, reorder, R(h->sx), R(h->sy), R(h->sz), h->sidx, h->t_off, h->t_end,
+              h->g, sp, h->tp, h->hull, ncol, reorder, (RecQuad *)h->srec, h->t_off, h->t_end,
               h->t_woff, h->t_oct, h->t_seg, R(h->rho), h->rho_part, fix_scale);
         }
       } else if (h->c.mk == 3) {
@@ -823,11 +831,11 @@ struct Pipe {
         const int grid = h->tp.ntiles + (int)(N / h->tp.chunk) + 1;
         if (h->std81)
           k_gather_tile81<T, 12, 20><<<grid, 256, tile_lds(h, 0, sizeof(T)), h->stream>>>(
-              h->g, hp, h->tp, h->last_rsd, R(h->sx), R(h->sy), R(h->sz), h->sidx, h->t_off, h->t_end, h->t_woff,
+              h->g, hp, h->tp, h->last_rsd, (RecQuad *)h->srec, h->t_off, h->t_end, h->t_woff,
               h->t_oct, h->t_seg, R(h->plike), R(h->V));
         else
           k_gather_tile<T><<<grid, 256, tile_lds(h, hp.ncol, sizeof(T)), h->stream>>>(
-              h->g, hp, h->tp, h->last_rsd, R(h->sx), R(h->sy), R(h->sz), h->sidx, h->t_off, h->t_end, h->t_woff,
+              h->g, hp, h->tp, h->last_rsd, (RecQuad *)h->srec, h->t_off, h->t_end, h->t_woff,
               h->t_oct, h->t_seg, R(h->plike), R(h->V));
       } else {
         k_gather_sph<T><<<nblk_full(N), 256, hp.ncol * sizeof(int4), h->stream>>>(h->g, make_pos(h, h->last_rsd), hp,
@@ -1178,8 +1186,7 @@ struct Pipe {
       std::vector<double> hp(6 * kRedBlocks);
       unsigned long long sd = 0;
       HIPCHK(hipMemcpyAsync(hp.data(), P, hp.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-      HIPCHK(hipMemcpyAsync(&sd, h->steps_done, sizeof sd, hipMemcpyDeviceToHost, h->stream));
-      HIPCHK(hipStreamSynchronize(h->stream));
+      CHK(read_ctl(h, &sd));
       done = sd;
       for (int t = 0; t < 6; t++) {
         double s = 0.;
@@ -1195,8 +1202,7 @@ struct Pipe {
       }
     } else {
       unsigned long long sd = 0;
-      HIPCHK(hipMemcpyAsync(&sd, h->steps_done, sizeof sd, hipMemcpyDeviceToHost, h->stream));
-      HIPCHK(hipStreamSynchronize(h->stream));
+      CHK(read_ctl(h, &sd));
       done = sd;
       // keep the proposal: energies_core re-transforms into (qk, pk), which reproduces it to round-off
       CHK(c2r_state(h, h->qk, h->ioq, h->dstage));
@@ -1715,10 +1721,7 @@ int bchmc_create(const bchmc_config *cfg, bchmc_handle **out) {
           CHK(dev_alloc(h, &h->t_end, (size_t)tp.ntiles));
           CHK(dev_alloc(h, &h->t_woff, (size_t)tp.ntiles + 1));
           CHK(dev_alloc(h, &h->t_rank, N));
-          CHK(dev_alloc_bytes(h, &h->sx, nrec * e));
-          CHK(dev_alloc_bytes(h, &h->sy, nrec * e));
-          CHK(dev_alloc_bytes(h, &h->sz, nrec * e));
-          CHK(dev_alloc(h, &h->sidx, nrec));
+          CHK(dev_alloc_bytes(h, &h->srec, nrec * 4 * e));
         }
       }
     }
@@ -1741,8 +1744,8 @@ void bchmc_destroy(bchmc_handle *h) {
   if (h->info) rocfft_execution_info_destroy(h->info);
   void *ptrs[] = {h->work,  h->wS,       h->wM,    h->qk,    h->pk,   h->gk,     h->Ck,         h->tC,   h->psi,
                   h->V,     h->rho,      h->plike, h->ioq,   h->iop,  h->gprior, h->glike,      h->conv, h->convF,
-                  h->dstage, h->rho_fix, h->cq, h->cp, h->qk2, h->pk2, h->xtw, h->part6, h->rho_part, h->partA, h->guard, h->stop, h->steps_done, h->hull,  h->t_cnt, h->t_off,
-                  h->t_woff, h->t_oct, h->t_seg, h->t_end, h->t_rank,  h->sx,    h->sy,    h->sz,   h->sidx};
+                  h->dstage, h->rho_fix, h->spec_bins, h->cq, h->cp, h->qk2, h->pk2, h->xtw, h->part6, h->rho_part, h->partA, h->guard, h->stop, h->steps_done, h->hull,  h->t_cnt, h->t_off,
+                  h->t_woff, h->t_oct, h->t_seg, h->t_end, h->t_rank,  h->srec};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   for (int f = 0; f < 6; f++)
@@ -1775,8 +1778,7 @@ int bchmc_upload(bchmc_handle *h, bchmc_field field, const double *host, size_t 
 int bchmc_sync(bchmc_handle *h) {
   if (!h) return BCHMC_ERR_ARG;
   ENTER(h);
-  HIPCHK(hipStreamSynchronize(h->stream));
-  return BCHMC_OK;
+  return read_ctl(h, nullptr);  // synchronises; also picks up the binning's overflow flag
 }
 
 void *bchmc_stream(bchmc_handle *h) { return h ? (void *)h->stream : nullptr; }
@@ -1792,8 +1794,7 @@ int bchmc_steps_done(bchmc_handle *h, uint64_t *steps_done) {
   if (!h || !steps_done) return BCHMC_ERR_ARG;
   ENTER(h);
   unsigned long long v = 0;
-  HIPCHK(hipMemcpyAsync(&v, h->steps_done, sizeof v, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
+  CHK(read_ctl(h, &v));
   *steps_done = v;
   return BCHMC_OK;
 }
@@ -2031,8 +2032,15 @@ int bchmc_measure_spectrum(bchmc_handle *h, const double *signal, uint64_t n_bin
     if (!h->have_cq) return h->fail(BCHMC_ERR_STATE, "no chain state: call bchmc_chain_set_state first");
     xk = h->cq;
   }
-  double *bins = nullptr;
-  CHK(dev_alloc(h, &bins, 3 * (size_t)n_bin));  // zero-filled
+  if (h->spec_cap < 3 * (size_t)n_bin) {  // kept in the handle: barcoderunner measures a spectrum after every sample
+    if (h->spec_bins) (void)hipFree(h->spec_bins);
+    h->spec_bins = nullptr;
+    h->spec_cap = 0;
+    CHK(dev_alloc(h, &h->spec_bins, 3 * (size_t)n_bin));
+    h->spec_cap = 3 * (size_t)n_bin;
+  }
+  double *bins = h->spec_bins;
+  HIPCHK(hipMemsetAsync(bins, 0, 3 * (size_t)n_bin * sizeof(double), h->stream));
   const Geo &g = h->g;
   const double knyq = g.kfac * (double)(g.n / 2);
   const double kmax = std::sqrt(knyq * knyq + knyq * knyq + knyq * knyq);
@@ -2048,7 +2056,6 @@ int bchmc_measure_spectrum(bchmc_handle *h, const double *signal, uint64_t n_bin
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipMemcpyAsync(hb.data(), bins, hb.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-  (void)hipFree(bins);
   if (e != hipSuccess) return h->fail(BCHMC_ERR_HIP, "measure_spectrum: %s", hipGetErrorString(e));
   const double N = (double)g.N, NORM = g.L * g.L * g.L / N / N;  // FOURIER_DEF_2, field_statistics.cpp:73-75
   for (uint64_t l = 0; l < n_bin; l++) {

@@ -45,6 +45,43 @@ __device__ __forceinline__ int subcell_octant(T x, T y, T z, T inv_d) {
 
 constexpr int kSortFlagNoScatter = 1 << 30;  // record flag: particle fails getDensity_SPH's domain test
 
+// Tile-sorted particle records, array of structures: { x, y, z, original index | flag } = 4 * sizeof(T) bytes (the index
+// sits in the low 32 bits of the fourth element).  One record is one 32-byte (fp64) or 16-byte (fp32) store in the
+// binning pass -- with four separate arrays the same record was four scattered 8- / 4-byte stores, and the octant-ordered
+// slots made the runs of neighbouring particles too short for the L2 to merge them -- and two (one) 16-byte loads in
+// the scatter / gather kernels.
+using RecQuad = uint4;  // 16 bytes
+template <typename T> __device__ __forceinline__ void rec_store(RecQuad *base, long long slot, T x, T y, T z, int idx);
+template <> __device__ __forceinline__ void rec_store<double>(RecQuad *base, long long slot, double x, double y, double z,
+                                                              int idx) {
+  double2 *b = reinterpret_cast<double2 *>(base) + 2 * slot;
+  b[0] = make_double2(x, y);
+  b[1] = make_double2(z, __longlong_as_double((long long)(unsigned)idx));
+}
+template <> __device__ __forceinline__ void rec_store<float>(RecQuad *base, long long slot, float x, float y, float z,
+                                                             int idx) {
+  reinterpret_cast<float4 *>(base)[slot] = make_float4(x, y, z, __int_as_float(idx));
+}
+template <typename T> __device__ __forceinline__ void rec_load(const RecQuad *base, long long slot, T &x, T &y, T &z, int &idx);
+template <> __device__ __forceinline__ void rec_load<double>(const RecQuad *base, long long slot, double &x, double &y,
+                                                             double &z, int &idx) {
+  const double2 *b = reinterpret_cast<const double2 *>(base) + 2 * slot;
+  const double2 a = b[0], c = b[1];
+  x = a.x;
+  y = a.y;
+  z = c.x;
+  idx = (int)__double_as_longlong(c.y);
+}
+template <> __device__ __forceinline__ void rec_load<float>(const RecQuad *base, long long slot, float &x, float &y, float &z,
+                                                            int &idx) {
+  const float4 v = reinterpret_cast<const float4 *>(base)[slot];
+  x = v.x;
+  y = v.y;
+  z = v.z;
+  idx = __float_as_int(v.w);
+}
+template <typename T> constexpr int rec_quads() { return sizeof(T) == 8 ? 2 : 1; }  // 16-byte units per record
+
 __device__ __forceinline__ int tile_of(const TilePar &tp, int n, long long ix, long long iy, long long iz) {
   const int cx = (int)(ix % n), cy = (int)(iy % n), cz = (int)(iz % n);
   return (cz / tp.tz) + tp.ntz * ((cy / tp.ty) + tp.nty * (cx / tp.tx));
@@ -118,15 +155,21 @@ __device__ __forceinline__ long long brick_particle(const Geo &g, int b, int &i,
 //   them back to about twice the per-tile number (k_bin_direct with one brick per table: 0.32 ms at 256^3, the per-tile
 //   binning it replaced: 0.25 ms).
 // k_bin (two-pass fallback, pass 1): tile id and arrival rank of every particle to tile_rank.
-constexpr int kBinPer = 4;
+#ifndef BCHMC_BIN_PER
+#define BCHMC_BIN_PER 4
+#endif
+constexpr int kBinPer = BCHMC_BIN_PER;
 
-// brick m (0..3) of super-brick sb: a 2 x 2 group in (i, j) when the bricks are 4 x 4 x 16, else four consecutive ones
+// brick m of super-brick sb: a PI x PJ group in (i, j) when the bricks are 4 x 4 x 16 (kBinPer = 1, 2 or 4), else
+// kBinPer consecutive ones
 __device__ __forceinline__ int super_brick(const Geo &g, int sb, int m) {
+  static_assert(kBinPer == 1 || kBinPer == 2 || kBinPer == 4, "kBinPer");
+  constexpr int PJ = kBinPer >= 2 ? 2 : 1, PI = kBinPer >= 4 ? 2 : 1;
   const int n = g.n;
   if ((n & 15) == 0) {
-    const int nbz = n >> 4, nby = n >> 2, nby2 = nby >> 1;
-    const int sbk = sb % nbz, sbj = (sb / nbz) % nby2, sbi = sb / (nbz * nby2);
-    return sbk + nbz * ((2 * sbj + (m & 1)) + nby * (2 * sbi + (m >> 1)));
+    const int nbz = n >> 4, nby = n >> 2, nbys = nby / PJ;
+    const int sbk = sb % nbz, sbj = (sb / nbz) % nbys, sbi = sb / (nbz * nbys);
+    return sbk + nbz * ((PJ * sbj + (m % PJ)) + nby * (PI * sbi + (m / PJ)));
   }
   return sb * kBinPer + m;  // may run past the last brick: brick_particle then returns p >= N
 }
@@ -134,8 +177,7 @@ __device__ __forceinline__ int super_brick(const Geo &g, int sb, int m) {
 template <typename T>
 __global__ void __launch_bounds__(256)
 k_bin_direct(Geo g, PosPar pp, SphPar sp, TilePar tp, int nsuper, const T *__restrict__ psi, int *__restrict__ cnt,
-             int *__restrict__ ovf, T *__restrict__ sx, T *__restrict__ sy, T *__restrict__ sz, int *__restrict__ sidx,
-             T *__restrict__ V, double *__restrict__ zero_part) {
+             int *__restrict__ ovf, RecQuad *__restrict__ srec, T *__restrict__ V, double *__restrict__ zero_part) {
   constexpr int kSlots = 2048;  // > kBinPer * 256 distinct counters can never occur: the probing always terminates
   __shared__ int hkey[kSlots], hcnt[kSlots], hbase[kSlots];
   // the scatter that follows accumulates sum(rho) into these partials: cleared here instead of by a fill launch
@@ -194,10 +236,7 @@ k_bin_direct(Geo g, PosPar pp, SphPar sp, TilePar tp, int nsuper, const T *__res
       } else {
         const int t = key[m] / kOct;
         const long long dst = (long long)t * tp.cap + (long long)(key[m] - t * kOct) * seg + rank;
-        sx[dst] = x[m];
-        sy[dst] = y[m];
-        sz[dst] = z[m];
-        sidx[dst] = (int)p[m] | flag[m];
+        rec_store<T>(srec, dst, x[m], y[m], z[m], (int)p[m] | flag[m]);
       }
     }
     __syncthreads();  // the hash table is reused by the next super-brick
@@ -351,8 +390,7 @@ k_scan_tiles(TilePar tp, const int *__restrict__ cnt_direct, const int *__restri
 template <typename T>
 __global__ void __launch_bounds__(256)
 k_reorder(Geo g, PosPar pp, int nbricks, const T *__restrict__ psi, const int2 *__restrict__ tile_rank,
-          const long long *__restrict__ off, const int *__restrict__ ovf, T *__restrict__ sx, T *__restrict__ sy,
-          T *__restrict__ sz, int *__restrict__ sidx) {
+          const long long *__restrict__ off, const int *__restrict__ ovf, RecQuad *__restrict__ srec) {
   if (!*ovf) return;  // the one-pass binning succeeded
   for (int brick = blockIdx.x; brick < nbricks; brick += gridDim.x) {
     int i, j, k;
@@ -363,10 +401,7 @@ k_reorder(Geo g, PosPar pp, int nbricks, const T *__restrict__ psi, const int2 *
     T x, y, z;
     particle_pos<T>(pp, i, j, k, psi[p], psi[p + g.N], psi[p + 2 * g.N], x, y, z);
     const long long slot = off[tr.x] + (tr.y & ~kSortFlagNoScatter);
-    sx[slot] = x;
-    sy[slot] = y;
-    sz[slot] = z;
-    sidx[slot] = (int)p | (tr.y & kSortFlagNoScatter);
+    rec_store<T>(srec, slot, x, y, z, (int)p | (tr.y & kSortFlagNoScatter));
   }
 }
 
@@ -442,7 +477,7 @@ __device__ __forceinline__ bool tile_work(const TilePar &tp, const long long *__
 // every candidate ANY of its lanes needs (81 unsorted, ~51 with octants, fewer with 4 x 4 x 4 bins).  Pure
 // reordering: results do not depend on it.  Requires chunk <= 256 * 8 and blockDim.x == 256.
 template <typename T>
-__device__ __forceinline__ void subsort_subcell(int bits, int pb, int pe, T inv_d, T *sx, T *sy, T *sz, int *sidx) {
+__device__ __forceinline__ void subsort_subcell(int bits, int pb, int pe, T inv_d, RecQuad *srec) {
   constexpr int kPer = 8;  // tp.chunk <= 256 * kPer
   __shared__ int hist[64], base[64];
   const int nb = 1 << (3 * bits);
@@ -455,10 +490,7 @@ __device__ __forceinline__ void subsort_subcell(int bits, int pb, int pe, T inv_
   for (int m = 0; m < kPer; m++) {
     const int s = pb + (int)threadIdx.x + 256 * m;
     if (s < pe) {
-      rx[m] = sx[s];
-      ry[m] = sy[s];
-      rz[m] = sz[s];
-      id[m] = sidx[s];
+      rec_load<T>(srec, s, rx[m], ry[m], rz[m], id[m]);
       const T fx = rx[m] * inv_d, fy = ry[m] * inv_d, fz = rz[m] * inv_d;  // ordering only
       const int ux = min((int)((fx - r_floor(fx)) * scale), (1 << bits) - 1);
       const int uy = min((int)((fy - r_floor(fy)) * scale), (1 << bits) - 1);
@@ -483,10 +515,7 @@ __device__ __forceinline__ void subsort_subcell(int bits, int pb, int pe, T inv_
     const int s = pb + (int)threadIdx.x + 256 * m;
     if (s < pe) {
       const int dst = pb + base[key[m]] + rank[m];
-      sx[dst] = rx[m];
-      sy[dst] = ry[m];
-      sz[dst] = rz[m];
-      sidx[dst] = id[m];
+      rec_store<T>(srec, dst, rx[m], ry[m], rz[m], id[m]);
     }
   }
   __threadfence_block();
@@ -506,8 +535,8 @@ __device__ __forceinline__ double flush_cell(long long *dst, long long v) {
 // getDensity_SPH on sorted particles: LDS accumulation per (tile, chunk), one flush.
 template <typename T, bool FIX>
 __global__ void __launch_bounds__(256)
-k_scatter_tile(Geo g, SphPar sp, TilePar tp, const int4 *__restrict__ cols, int ncol, int reorder, T *sx, T *sy, T *sz,
-               int *sidx, const long long *__restrict__ off, const long long *__restrict__ tend, const int *__restrict__ woff,
+k_scatter_tile(Geo g, SphPar sp, TilePar tp, const int4 *__restrict__ cols, int ncol, int reorder, RecQuad *srec,
+               const long long *__restrict__ off, const long long *__restrict__ tend, const int *__restrict__ woff,
                const int4 *__restrict__ oct, const int *__restrict__ seg_in,
                typename Cell<FIX, T>::type *__restrict__ rho, double *__restrict__ rho_part, double fix_scale) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw_scatter[];
@@ -518,10 +547,7 @@ k_scatter_tile(Geo g, SphPar sp, TilePar tp, const int4 *__restrict__ cols, int 
   long long rec0;
   OctMap om;
   if (!tile_work(tp, off, tend, woff, oct, seg_in, tile, rec0, pb, pe, om)) return;
-  sx += rec0;  // this tile's record slots; pb, pe are relative to them
-  sy += rec0;
-  sz += rec0;
-  sidx += rec0;
+  srec += rec0 * rec_quads<T>();  // this tile's record slots; pb, pe are relative to them
   const int ncell = tp.lx * tp.ly * tp.lz;
   int4 *s_cols = reinterpret_cast<int4 *>(s_raw_scatter + (((size_t)ncell * sizeof(double) + 15) & ~(size_t)15));
   for (int m = threadIdx.x; m < ncol; m += blockDim.x) s_cols[m] = cols[m];
@@ -529,16 +555,17 @@ k_scatter_tile(Geo g, SphPar sp, TilePar tp, const int4 *__restrict__ cols, int 
   const T d = (T)g.d;
   const HomeCell<T> hc = make_home<T>(g);
   // the one-pass binning delivers the records ordered by octant; after a fallback sort they are ordered here
-  if (reorder && om.seg == 0) subsort_subcell<T>(reorder, pb, pe, hc.inv_d, sx, sy, sz, sidx);
+  if (reorder && om.seg == 0) subsort_subcell<T>(reorder, pb, pe, hc.inv_d, srec);
   __syncthreads();
   const int tzi = tile % tp.ntz, tyi = (tile / tp.ntz) % tp.nty, txi = tile / (tp.ntz * tp.nty);
   const int ox = txi * tp.tx - tp.R, oy = tyi * tp.ty - tp.R, oz = tzi * tp.tz - tp.R;  // global cell of LDS (0,0,0)
   const int n = g.n, R = sp.reach;
   const T r2_lim = (T)sp.r2_lim, h_inv = (T)sp.h_inv, w_norm = (T)sp.w_norm;
   for (int s = pb + threadIdx.x; s < pe; s += blockDim.x) {
-    const int r = om.slot(s);
-    if (sidx[r] & kSortFlagNoScatter) continue;
-    const T x = sx[r], y = sy[r], z = sz[r];
+    T x, y, z;
+    int rid;
+    rec_load<T>(srec, om.slot(s), x, y, z, rid);
+    if (rid & kSortFlagNoScatter) continue;
     const int ix = home_cell_i(hc, x), iy = home_cell_i(hc, y), iz = home_cell_i(hc, z);
     const T ccx = ((T)ix + T(0.5)) * d, ccy = ((T)iy + T(0.5)) * d, ccz = ((T)iz + T(0.5)) * d;
     const int hx = wrap_cell(ix, n) - ox, hy = wrap_cell(iy, n) - oy, hz = wrap_cell(iz, n) - oz;  // home cell in LDS coords
@@ -604,8 +631,8 @@ k_scatter_tile(Geo g, SphPar sp, TilePar tp, const int4 *__restrict__ cols, int 
 // likelihood_calc_V_SPH on sorted particles: part_like tile + halo staged in LDS.
 template <typename T>
 __global__ void __launch_bounds__(256)
-k_gather_tile(Geo g, HullPar hp, TilePar tp, int rsd, const T *__restrict__ sx, const T *__restrict__ sy,
-              const T *__restrict__ sz, const int *__restrict__ sidx, const long long *__restrict__ off,
+k_gather_tile(Geo g, HullPar hp, TilePar tp, int rsd, const RecQuad *__restrict__ srec,
+              const long long *__restrict__ off,
               const long long *__restrict__ tend, const int *__restrict__ woff, const int4 *__restrict__ oct,
               const int *__restrict__ seg_in, const T *__restrict__ plike, T *__restrict__ V) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw_gather[];
@@ -614,10 +641,7 @@ k_gather_tile(Geo g, HullPar hp, TilePar tp, int rsd, const T *__restrict__ sx, 
   long long rec0;
   OctMap om;
   if (!tile_work(tp, off, tend, woff, oct, seg_in, tile, rec0, pb, pe, om)) return;
-  sx += rec0;  // this tile's record slots; pb, pe are relative to them
-  sy += rec0;
-  sz += rec0;
-  sidx += rec0;
+  srec += rec0 * rec_quads<T>();  // this tile's record slots; pb, pe are relative to them
   const int ncell = tp.lx * tp.ly * tp.lz;
   int4 *s_cols = reinterpret_cast<int4 *>(s_raw_gather + (((size_t)ncell * sizeof(T) + 15) & ~(size_t)15));
   for (int m = threadIdx.x; m < hp.ncol; m += blockDim.x) s_cols[m] = hp.cols[m];
@@ -633,8 +657,9 @@ k_gather_tile(Geo g, HullPar hp, TilePar tp, int rsd, const T *__restrict__ sx, 
   const T d_h = (T)hp.d_h, h_inv = (T)hp.h_inv, norm = (T)hp.norm;
   const HomeCell<T> hc = make_home<T>(g);
   for (int s = pb + threadIdx.x; s < pe; s += blockDim.x) {
-    const int r = om.slot(s);
-    const T px = sx[r], py = sy[r], pz = sz[r];
+    T px, py, pz;
+    int rid;
+    rec_load<T>(srec, om.slot(s), px, py, pz, rid);
     const int ix = home_cell_i(hc, px), iy = home_cell_i(hc, py), iz = home_cell_i(hc, pz);
     const T dpcx = px * h_inv - ((T)ix + T(0.5)) * d_h;
     const T dpcy = py * h_inv - ((T)iy + T(0.5)) * d_h;
@@ -667,7 +692,7 @@ k_gather_tile(Geo g, HullPar hp, TilePar tp, int rsd, const T *__restrict__ sx, 
     vy *= normalize;
     vz *= normalize;
     if (rsd) vz += (T)hp.f1 * vz;
-    const long long p = sidx[r] & ~kSortFlagNoScatter;
+    const long long p = rid & ~kSortFlagNoScatter;
     V[p] = vx;
     V[p + g.N] = vy;
     V[p + 2 * g.N] = vz;
@@ -700,7 +725,7 @@ __host__ __device__ constexpr int hull81_zw(int a, int b) {
 #endif
 template <typename T, int LY, int LZ, bool FIX>
 __global__ void __launch_bounds__(256, BCHMC_SCATTER_WAVES)
-k_scatter_tile81(Geo g, SphPar sp, TilePar tp, int reorder, T *sx, T *sy, T *sz, int *sidx,
+k_scatter_tile81(Geo g, SphPar sp, TilePar tp, int reorder, RecQuad *srec,
                  const long long *__restrict__ off, const long long *__restrict__ tend, const int *__restrict__ woff,
                  const int4 *__restrict__ oct, const int *__restrict__ seg_in,
                  typename Cell<FIX, T>::type *__restrict__ rho, double *__restrict__ rho_part, int *__restrict__ cnt_zero,
@@ -719,16 +744,13 @@ k_scatter_tile81(Geo g, SphPar sp, TilePar tp, int reorder, T *sx, T *sy, T *sz,
   long long rec0;
   OctMap om;
   if (!tile_work(tp, off, tend, woff, oct, seg_in, tile, rec0, pb, pe, om)) return;
-  sx += rec0;  // this tile's record slots; pb, pe are relative to them
-  sy += rec0;
-  sz += rec0;
-  sidx += rec0;
+  srec += rec0 * rec_quads<T>();  // this tile's record slots; pb, pe are relative to them
   const int ncell = tp.lx * LY * LZ;
   for (int c = threadIdx.x; c < ncell; c += blockDim.x) s_tile_acc[c] = Acc(0);
   const T d = (T)g.d;
   const HomeCell<T> hc = make_home<T>(g);
   // the one-pass binning delivers the records ordered by octant; after a fallback sort they are ordered here
-  if (reorder && om.seg == 0) subsort_subcell<T>(reorder, pb, pe, hc.inv_d, sx, sy, sz, sidx);
+  if (reorder && om.seg == 0) subsort_subcell<T>(reorder, pb, pe, hc.inv_d, srec);
   __syncthreads();
   const int tzi = tile % tp.ntz, tyi = (tile / tp.ntz) % tp.nty, txi = tile / (tp.ntz * tp.nty);
   const int ox = txi * tp.tx - 2, oy = tyi * tp.ty - 2, oz = tzi * tp.tz - 2;  // global cell of LDS (0,0,0)
@@ -739,9 +761,10 @@ k_scatter_tile81(Geo g, SphPar sp, TilePar tp, int reorder, T *sx, T *sy, T *sz,
   const T q2_lim = (T)(sp.r2_lim * sp.h_inv * sp.h_inv);
   const T c34w = T(0.75) * w_norm, c32w = T(-1.5) * w_norm, c14w = T(0.25) * w_norm;
   for (int s = pb + threadIdx.x; s < pe; s += blockDim.x) {
-    const int r = om.slot(s);
-    if (sidx[r] & kSortFlagNoScatter) continue;
-    const T x = sx[r], y = sy[r], z = sz[r];
+    T x, y, z;
+    int rid;
+    rec_load<T>(srec, om.slot(s), x, y, z, rid);
+    if (rid & kSortFlagNoScatter) continue;
     const int ix = home_cell_i(hc, x), iy = home_cell_i(hc, y), iz = home_cell_i(hc, z);
     const T ccx = ((T)ix + T(0.5)) * d, ccy = ((T)iy + T(0.5)) * d, ccz = ((T)iz + T(0.5)) * d;
     const int hx = wrap_cell(ix, n) - ox, hy = wrap_cell(iy, n) - oy, hz = wrap_cell(iz, n) - oz;  // home cell in LDS coords
@@ -804,8 +827,8 @@ k_scatter_tile81(Geo g, SphPar sp, TilePar tp, int reorder, T *sx, T *sy, T *sz,
 
 template <typename T, int LY, int LZ>
 __global__ void __launch_bounds__(256, BCHMC_GATHER_WAVES)
-k_gather_tile81(Geo g, HullPar hp, TilePar tp, int rsd, const T *__restrict__ sx, const T *__restrict__ sy,
-                const T *__restrict__ sz, const int *__restrict__ sidx, const long long *__restrict__ off,
+k_gather_tile81(Geo g, HullPar hp, TilePar tp, int rsd, const RecQuad *__restrict__ srec,
+                const long long *__restrict__ off,
                 const long long *__restrict__ tend, const int *__restrict__ woff, const int4 *__restrict__ oct,
                 const int *__restrict__ seg_in, const T *__restrict__ plike, T *__restrict__ V) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw_gather81[];
@@ -814,10 +837,7 @@ k_gather_tile81(Geo g, HullPar hp, TilePar tp, int rsd, const T *__restrict__ sx
   long long rec0;
   OctMap om;
   if (!tile_work(tp, off, tend, woff, oct, seg_in, tile, rec0, pb, pe, om)) return;
-  sx += rec0;  // this tile's record slots; pb, pe are relative to them
-  sy += rec0;
-  sz += rec0;
-  sidx += rec0;
+  srec += rec0 * rec_quads<T>();  // this tile's record slots; pb, pe are relative to them
   const int ncell = tp.lx * LY * LZ;
   const int n = g.n;
   const int tzi = tile % tp.ntz, tyi = (tile / tp.ntz) % tp.nty, txi = tile / (tp.ntz * tp.nty);
@@ -831,8 +851,9 @@ k_gather_tile81(Geo g, HullPar hp, TilePar tp, int rsd, const T *__restrict__ sx
   const T d_h = (T)hp.d_h, h_inv = (T)hp.h_inv, norm = (T)hp.norm;
   const HomeCell<T> hc = make_home<T>(g);
   for (int s = pb + threadIdx.x; s < pe; s += blockDim.x) {
-    const int r = om.slot(s);
-    const T px = sx[r], py = sy[r], pz = sz[r];
+    T px, py, pz;
+    int rid;
+    rec_load<T>(srec, om.slot(s), px, py, pz, rid);
     const int ix = home_cell_i(hc, px), iy = home_cell_i(hc, py), iz = home_cell_i(hc, pz);
     const T dpcx = px * h_inv - ((T)ix + T(0.5)) * d_h;
     const T dpcy = py * h_inv - ((T)iy + T(0.5)) * d_h;
@@ -893,7 +914,7 @@ k_gather_tile81(Geo g, HullPar hp, TilePar tp, int rsd, const T *__restrict__ sx
     vy *= normalize;
     vz *= normalize;
     if (rsd) vz += (T)hp.f1 * vz;
-    const long long p = sidx[r] & ~kSortFlagNoScatter;
+    const long long p = rid & ~kSortFlagNoScatter;
     V[p] = vx;
     V[p + g.N] = vy;
     V[p + 2 * g.N] = vz;

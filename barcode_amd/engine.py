@@ -218,8 +218,10 @@ class Engine:
         return out
 
     # ---- host-array entry points (what the reference shim binds) ---------------------------------
-    def leapfrog(self, q0, p0, eps, neps):
-        q1, p1 = np.empty(self.N), np.empty(self.N)
+    def leapfrog(self, q0, p0, eps, neps, out=None):
+        """``out=(q1, p1)``: caller-owned result arrays (the reference allocates signalf / momentaf once per sample,
+        HMC.cc:375); fresh arrays otherwise."""
+        q1, p1 = out if out is not None else (np.empty(self.N), np.empty(self.N))
         done = C.c_uint64()
         self._chk(self.lib.bchmc_leapfrog(self.h, _p(self._in(q0)), _p(self._in(p0)), _p(q1), _p(p1), float(eps),
                                           int(neps), C.byref(done)))

@@ -25,10 +25,11 @@ w, s, nobs = inputs.mock_observations(p, e.fetch("deltaX").reshape((nx,) * 3))
 e.upload(window=w, noise=s, nobs=nobs)
 eps = 0.5 * p.eps_heuristic()
 q0, p0 = f["q0"].ravel().copy(), f["p0"].ravel().copy()
+q1, p1 = np.zeros(p.N), np.zeros(p.N)   # signalf / momentaf: allocated once per sample upstream (HMC.cc:375)
 
 
 def host_path():
-    q1, p1, _ = e.leapfrog(q0, p0, eps, neps)
+    e.leapfrog(q0, p0, eps, neps, out=(q1, p1))
     return e.delta_hamiltonian(q0, p0, q1, p1)[0]
 
 
@@ -50,6 +51,16 @@ t1 = time.perf_counter()
 for i in range(reps):
     chain_path(i + 1)
 t2 = time.perf_counter()
+import os  # noqa: E402
+os.environ["BCHMC_NO_DH_CACHE"] = "1"   # the r01 protocol: plain trajectory, then two full energy evaluations
+host_path()
+t3 = time.perf_counter()
+for _ in range(reps):
+    host_path()
+t4 = time.perf_counter()
 print(json.dumps(dict(grid=nx, neps=neps, host_array_ms_per_attempt=1e3 * (t1 - t0) / reps,
                       resident_chain_ms_per_attempt=1e3 * (t2 - t1) / reps,
-                      note="host path excludes the host-side momentum draw the reference does per attempt")))
+                      host_array_without_trajectory_reuse_ms=1e3 * (t4 - t3) / reps,
+                      note="host path = bchmc_leapfrog + bchmc_delta_hamiltonian on caller arrays (pinned staging, "
+                           "energies taken from the trajectory's own pass); excludes the host-side momentum draw the "
+                           "reference does per attempt")))
