@@ -39,8 +39,12 @@ constexpr int kOct = 8;  // sub-cell octants: (x, y, z) in the upper half of the
 template <typename T>
 __device__ __forceinline__ int subcell_octant(T x, T y, T z, T inv_d) {
   const T fx = x * inv_d, fy = y * inv_d, fz = z * inv_d;
-  return ((fx - r_floor(fx) >= T(0.5)) ? 4 : 0) | ((fy - r_floor(fy) >= T(0.5)) ? 2 : 0) |
-         ((fz - r_floor(fz) >= T(0.5)) ? 1 : 0);
+  const int b = ((fx - r_floor(fx) >= T(0.5)) ? 4 : 0) | ((fy - r_floor(fy) >= T(0.5)) ? 2 : 0) |
+                ((fz - r_floor(fz) >= T(0.5)) ? 1 : 0);
+  // position of b in the 3-bit Gray sequence: consecutive segments are octants that differ along ONE axis, so a wave
+  // that straddles a segment boundary (segment lengths are not multiples of 64) pays for the union of two adjacent
+  // octants, not of two opposite ones
+  return b ^ (b >> 1) ^ (b >> 2);
 }
 
 constexpr int kSortFlagNoScatter = 1 << 30;  // record flag: particle fails getDensity_SPH's domain test

@@ -57,12 +57,29 @@ def main():
         tot_w += w
     grid = int(sys.argv[5]) if len(sys.argv) > 5 else 256
     precision = sys.argv[6] if len(sys.argv) > 6 else "fp64"
+    # Calibration of the x2 FETCH_SIZE correction on kernels whose streamed bytes are known exactly (8 B per lane
+    # reads, not the 16 B per lane the microarch guide calibrated): R = one real array.
+    R = grid ** 3 * (8 if precision == "fp64" else 4)
+    known = {"k_bin_direct": (3 * R, None), "k_bin<double, true>": (3 * R, None), "k_bin<float, true>": (3 * R, None),
+             "k_partial_like": (4 * R, 1 * R)}
+    check = {}
+    for n, k in kernels.items():
+        for pref, (rd, wr) in known.items():
+            if n.startswith(pref) and k["launches_per_step"] > 0:
+                got_r = k["read_MB_per_step"] * 1e6 / k["launches_per_step"]
+                check[n] = dict(read_expected_MB=round(rd / 1e6, 1), read_counter_x2_MB=round(got_r / 1e6, 1),
+                                ratio=round(got_r / rd, 4))
+                if wr:
+                    got_w = k["write_MB_per_step"] * 1e6 / k["launches_per_step"]
+                    check[n].update(write_expected_MB=round(wr / 1e6, 1), write_counter_MB=round(got_w / 1e6, 1))
     out = dict(grid=grid, precision=precision, steps=steps, hbm_read_bytes_per_step=tot_r, hbm_write_bytes_per_step=tot_w,
-               hbm_bytes_per_step=tot_r + tot_w, fetch_size_correction=2.0, kernels=kernels)
+               hbm_bytes_per_step=tot_r + tot_w, fetch_size_correction=2.0, fetch_size_check=check, kernels=kernels)
     print("%-34s %10s %10s %8s" % ("kernel", "read MB", "write MB", "launches"))
     for n, k in kernels.items():
         print("%-34s %10.1f %10.1f %8.2f" % (n, k["read_MB_per_step"], k["write_MB_per_step"], k["launches_per_step"]))
     print("total per step: read %.1f MB, write %.1f MB, sum %.3f GB" % (tot_r / 1e6, tot_w / 1e6, (tot_r + tot_w) / 1e9))
+    for n, c in check.items():
+        print("FETCH_SIZE x2 check on %s: %s" % (n, c))
     if len(sys.argv) > 4:
         json.dump(out, open(sys.argv[4], "w"), indent=1)
 
