@@ -802,11 +802,21 @@ k_scatter_tile81(Geo g, SphPar sp, TilePar tp, int reorder, RecQuad *srec,
             T rq;
             const T q = sqrt_rsq(q2, rq);
             // SPH_kernel_3D (massFunctions.cc:366-384): w (1 - 3/2 q^2 + 3/4 q^3) for q <= 1, w/4 (2 - q)^3 up to
-            // q = 2; a q that rounding left a hair above 2 contributes exactly 0, like the reference's `r/h <= 2`
-            const T inner = r_fma(q2, r_fma(c34w, q, c32w), w_norm);
-            const T t = r_max(T(2) - q, T(0));
-            const T outer = (c14w * t) * (t * t);
-            cell_add(row + c, (double)((q2 <= T(1)) ? inner : outer), fix_scale);
+            // q = 2; a q that rounding left a hair above 2 contributes exactly 0, like the reference's `r/h <= 2`.
+            // Which branch a candidate can take is known when the loops unroll (h = d, offset from the home centre
+            // within half a cell): a cell two away along any axis is at q >= 1.5 -- outer branch only; the home cell
+            // is at q <= 0.87 -- inner branch only; only the other 26 need both and the select.
+            const bool far = (a == 0 || a == 4 || b == 0 || b == 4 || c == 0 || c == 4);
+            const bool home = (a == 2 && b == 2 && c == 2);
+            T val;
+            if (home) {
+              val = r_fma(q2, r_fma(c34w, q, c32w), w_norm);
+            } else {
+              const T t = r_max(T(2) - q, T(0));
+              const T outer = (c14w * t) * (t * t);
+              val = far ? outer : ((q2 <= T(1)) ? r_fma(q2, r_fma(c34w, q, c32w), w_norm) : outer);
+            }
+            cell_add(row + c, (double)val, fix_scale);
           }
         }
       }
@@ -902,8 +912,18 @@ k_gather_tile81(Geo g, HullPar hp, TilePar tp, int rsd, const RecQuad *__restric
               // grad_SPH_kernel_3D_h_units (SPH_kernel.cpp:148-208): dW/dq / q
               T rq;
               const T q = sqrt_rsq(q_sq, rq);
-              const T qm2 = q - T(2);
-              const T gr = (q_sq > T(1)) ? ((qm2 * qm2) * c34n) * rq : r_fma(c225n, q, c3n);
+              // the branch is known at unroll time for the cells two away (q >= 1.5: outer) and the home cell
+              // (q <= 0.87: inner), see k_scatter_tile81
+              const bool far = (a == 0 || a == 4 || b == 0 || b == 4 || c == 0 || c == 4);
+              const bool home = (a == 2 && b == 2 && c == 2);
+              T gr;
+              if (home) {
+                gr = r_fma(c225n, q, c3n);
+              } else {
+                const T qm2 = q - T(2);
+                const T outer = ((qm2 * qm2) * c34n) * rq;
+                gr = far ? outer : ((q_sq > T(1)) ? outer : r_fma(c225n, q, c3n));
+              }
               const T common = pl[c] * gr;
               vx += common * xh[a];
               vy += common * yh[b];
