@@ -697,6 +697,11 @@ struct Pipe {
         // sub-cell ordering inside each work item: binary digits per axis (BCHMC_SUBSORT_BITS = 0 / 1 / 2)
         const char *sb = std::getenv("BCHMC_SUBSORT_BITS");
         const int reorder = (h->tp.chunk > 2048) ? 0 : (sb ? std::min(std::max(atoi(sb), 0), 2) : 2);
+        if (reorder) {  // orders the records only after a fallback sort; returns at once otherwise
+          k_subsort<T><<<512, 256, 0, h->stream>>>(h->g, h->tp, reorder, (RecQuad *)h->srec, h->t_off, h->t_end, h->t_woff,
+                                                   h->t_oct, h->t_seg);
+          HIPCHK(hipGetLastError());
+        }
         if (h->std81) {
           if (h->fix)
             k_scatter_tile81<T, 12, 20, true><<<grid, 256, tile_lds(h, 0, sizeof(double)), h->stream>>>(

@@ -429,7 +429,7 @@ struct OctMap {
 };
 
 // Work item -> (tile, particle range).  Returns false when this workgroup has nothing to do.
-__device__ __forceinline__ bool tile_work(const TilePar &tp, const long long *__restrict__ off,
+__device__ __forceinline__ bool tile_work(int w, const TilePar &tp, const long long *__restrict__ off,
                                           const long long *__restrict__ tend, const int *__restrict__ woff,
                                           const int4 *__restrict__ oct, const int *__restrict__ seg_in, int &tile,
                                           long long &base, int &p_begin, int &p_end, OctMap &om) {
@@ -438,7 +438,6 @@ __device__ __forceinline__ bool tile_work(const TilePar &tp, const long long *__
   __shared__ long long s_base;
   __shared__ int s_oct[kOct + 1];
   if (threadIdx.x == 0) {
-    const int w = blockIdx.x;
     int t = -1, b = 0, e = 0;
     long long o = 0;
     if (w < woff[tp.ntiles]) {
@@ -525,6 +524,27 @@ __device__ __forceinline__ void subsort_subcell(int bits, int pb, int pe, T inv_
   __threadfence_block();
 }
 
+// After a FALLBACK sort the records of a tile are contiguous but in arrival order: this pass orders every work item's
+// records by sub-cell bin for the scatter and the gather (the one-pass binning delivers octant order by construction, so
+// the kernel returns at once then; a separate kernel so that the scatter does not carry its 70 record registers).
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_subsort(Geo g, TilePar tp, int bits, RecQuad *srec_all, const long long *__restrict__ off,
+          const long long *__restrict__ tend, const int *__restrict__ woff, const int4 *__restrict__ oct,
+          const int *__restrict__ seg_in) {
+  if (*seg_in != 0 || bits <= 0) return;
+  const int nitems = woff[tp.ntiles];
+  const HomeCell<T> hc = make_home<T>(g);
+  for (int w = blockIdx.x; w < nitems; w += gridDim.x) {
+    int tile, pb, pe;
+    long long rec0;
+    OctMap om;
+    if (tile_work(w, tp, off, tend, woff, oct, seg_in, tile, rec0, pb, pe, om))
+      subsort_subcell<T>(bits, pb, pe, hc.inv_d, srec_all + rec0 * rec_quads<T>());
+    __syncthreads();  // tile_work's and the sort's LDS are reused by the next work item
+  }
+}
+
 // One LDS cell of a work item into the global density; returns what the default mode adds to its running sum(rho).
 template <typename T>
 __device__ __forceinline__ double flush_cell(T *dst, double v) {
@@ -550,7 +570,7 @@ k_scatter_tile(Geo g, SphPar sp, TilePar tp, const int4 *__restrict__ cols, int 
   int tile, pb, pe;
   long long rec0;
   OctMap om;
-  if (!tile_work(tp, off, tend, woff, oct, seg_in, tile, rec0, pb, pe, om)) return;
+  if (!tile_work((int)blockIdx.x, tp, off, tend, woff, oct, seg_in, tile, rec0, pb, pe, om)) return;
   srec += rec0 * rec_quads<T>();  // this tile's record slots; pb, pe are relative to them
   const int ncell = tp.lx * tp.ly * tp.lz;
   int4 *s_cols = reinterpret_cast<int4 *>(s_raw_scatter + (((size_t)ncell * sizeof(double) + 15) & ~(size_t)15));
@@ -558,8 +578,6 @@ k_scatter_tile(Geo g, SphPar sp, TilePar tp, const int4 *__restrict__ cols, int 
   for (int c = threadIdx.x; c < ncell; c += blockDim.x) s_tile_acc[c] = Acc(0);
   const T d = (T)g.d;
   const HomeCell<T> hc = make_home<T>(g);
-  // the one-pass binning delivers the records ordered by octant; after a fallback sort they are ordered here
-  if (reorder && om.seg == 0) subsort_subcell<T>(reorder, pb, pe, hc.inv_d, srec);
   __syncthreads();
   const int tzi = tile % tp.ntz, tyi = (tile / tp.ntz) % tp.nty, txi = tile / (tp.ntz * tp.nty);
   const int ox = txi * tp.tx - tp.R, oy = tyi * tp.ty - tp.R, oz = tzi * tp.tz - tp.R;  // global cell of LDS (0,0,0)
@@ -644,7 +662,7 @@ k_gather_tile(Geo g, HullPar hp, TilePar tp, int rsd, const RecQuad *__restrict_
   int tile, pb, pe;
   long long rec0;
   OctMap om;
-  if (!tile_work(tp, off, tend, woff, oct, seg_in, tile, rec0, pb, pe, om)) return;
+  if (!tile_work((int)blockIdx.x, tp, off, tend, woff, oct, seg_in, tile, rec0, pb, pe, om)) return;
   srec += rec0 * rec_quads<T>();  // this tile's record slots; pb, pe are relative to them
   const int ncell = tp.lx * tp.ly * tp.lz;
   int4 *s_cols = reinterpret_cast<int4 *>(s_raw_gather + (((size_t)ncell * sizeof(T) + 15) & ~(size_t)15));
@@ -747,14 +765,12 @@ k_scatter_tile81(Geo g, SphPar sp, TilePar tp, int reorder, RecQuad *srec,
   int tile, pb, pe;
   long long rec0;
   OctMap om;
-  if (!tile_work(tp, off, tend, woff, oct, seg_in, tile, rec0, pb, pe, om)) return;
+  if (!tile_work((int)blockIdx.x, tp, off, tend, woff, oct, seg_in, tile, rec0, pb, pe, om)) return;
   srec += rec0 * rec_quads<T>();  // this tile's record slots; pb, pe are relative to them
   const int ncell = tp.lx * LY * LZ;
   for (int c = threadIdx.x; c < ncell; c += blockDim.x) s_tile_acc[c] = Acc(0);
   const T d = (T)g.d;
   const HomeCell<T> hc = make_home<T>(g);
-  // the one-pass binning delivers the records ordered by octant; after a fallback sort they are ordered here
-  if (reorder && om.seg == 0) subsort_subcell<T>(reorder, pb, pe, hc.inv_d, srec);
   __syncthreads();
   const int tzi = tile % tp.ntz, tyi = (tile / tp.ntz) % tp.nty, txi = tile / (tp.ntz * tp.nty);
   const int ox = txi * tp.tx - 2, oy = tyi * tp.ty - 2, oz = tzi * tp.tz - 2;  // global cell of LDS (0,0,0)
@@ -850,7 +866,7 @@ k_gather_tile81(Geo g, HullPar hp, TilePar tp, int rsd, const RecQuad *__restric
   int tile, pb, pe;
   long long rec0;
   OctMap om;
-  if (!tile_work(tp, off, tend, woff, oct, seg_in, tile, rec0, pb, pe, om)) return;
+  if (!tile_work((int)blockIdx.x, tp, off, tend, woff, oct, seg_in, tile, rec0, pb, pe, om)) return;
   srec += rec0 * rec_quads<T>();  // this tile's record slots; pb, pe are relative to them
   const int ncell = tp.lx * LY * LZ;
   const int n = g.n;
