@@ -660,9 +660,10 @@ struct Pipe {
       int *cnt1 = h->t_cnt, *cnt2 = h->t_cnt + kOct * nt, *ovf = h->t_cnt + (kOct + 1) * nt;  // ovf[1] is sticky, see grow_sort_slots
       if (!h->cnt_clean) HIPCHK(hipMemsetAsync(h->t_cnt, 0, ((kOct + 1) * (size_t)nt + 1) * sizeof(int), h->stream));
       h->cnt_clean = false;
-      // the two fallback kernels return at once unless a tile overflowed: a small grid striding over the bricks keeps
-      // their launches cheap (at 256^3 the 4096-workgroup launches of two no-op kernels cost 30 us per step)
-      const int fb_grid = h->sort_direct ? std::min(nbricks, 512) : nbricks;
+      // the two fallback kernels return at once unless a tile overflowed; when one did (every step until the slots are
+      // doubled at the next trajectory start) they must still fill the chip, so the grid is capped, not tiny: with 512
+      // workgroups a 512^3 step in fallback mode took 69 ms instead of 22 (and the no-op launches cost 18-20 us either way)
+      const int fb_grid = h->sort_direct ? std::min(nbricks, 4096) : nbricks;
       if (h->sort_direct) {
         const int nsuper = (nbricks + kBinPer - 1) / kBinPer;
         k_bin_direct<T><<<nsuper, 256, 0, h->stream>>>(h->g, pp, sp, h->tp, nsuper, R(h->psi), cnt1, ovf,
@@ -698,7 +699,7 @@ struct Pipe {
         const char *sb = std::getenv("BCHMC_SUBSORT_BITS");
         const int reorder = (h->tp.chunk > 2048) ? 0 : (sb ? std::min(std::max(atoi(sb), 0), 2) : 2);
         if (reorder) {  // orders the records only after a fallback sort; returns at once otherwise
-          k_subsort<T><<<512, 256, 0, h->stream>>>(h->g, h->tp, reorder, (RecQuad *)h->srec, h->t_off, h->t_end, h->t_woff,
+          k_subsort<T><<<std::min(grid, 8192), 256, 0, h->stream>>>(h->g, h->tp, reorder, (RecQuad *)h->srec, h->t_off, h->t_end, h->t_woff,
                                                    h->t_oct, h->t_seg);
           HIPCHK(hipGetLastError());
         }
