@@ -19,6 +19,25 @@ PLANCK_TABLE = os.path.join(DATA_DIR, "PLANCK_CAMB.dat")
 SEED_TRUTH, SEED_NOBS, SEED_Q0, SEED_P0 = 1001, 1002, 1003, 1004
 
 
+def host_cpu_share():
+    """CPUs this process may actually use: the affinity mask capped by the cgroup's CPU quota (a GPU box shows all 256
+    hardware threads of its host and grants about 16 of them; thread pools sized by the visible count spin against the
+    quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def _workers():
+    """Threads for the big-grid FFTs."""
+    return min(host_cpu_share(), 32)
+
+
 def _rng(seed):
     return np.random.Generator(np.random.Philox(seed))
 
@@ -63,10 +82,11 @@ def gaussian_random_field(params, spectrum, seed, scale=1.0):
         # not matter, every consumer of a case reads the same arrays).  Small grids keep numpy: the golden fixtures
         # were generated with it.
         from scipy import fft as sfft
-        wk = sfft.rfftn(white, workers=-1)
+        nw = _workers()
+        wk = sfft.rfftn(white, workers=nw)
         del white
         wk *= amp
-        f = sfft.irfftn(wk, s=(n, n, n), axes=(0, 1, 2), workers=-1, overwrite_x=True)
+        f = sfft.irfftn(wk, s=(n, n, n), axes=(0, 1, 2), workers=nw, overwrite_x=True)
     else:
         wk = np.fft.rfftn(white)
         f = np.fft.irfftn(wk * amp, s=(n, n, n), axes=(0, 1, 2))

@@ -84,8 +84,8 @@ def cpu_baseline(params, case_arrays, q0, p0, eps, reps=3):
     Returns (json object, (q1, p1) of the oracle's 3-step trajectory for the parity-at-size check)."""
     import numpy as np
     from oracle.oracle import Oracle
-    cores = int(os.environ.get("OMP_NUM_THREADS", "1"))
     o = Oracle(params, omp=True)
+    cores = int(o.lib.orc_get_max_threads())
     o.set(**case_arrays)
     per_step, total, traj3 = [], 0.0, None
     for _ in range(reps):
@@ -180,11 +180,10 @@ def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args)  # parent: no torch.cuda / engine call has happened or will happen here
-    # host threads for the CPU baseline (must be set before the OpenMP library loads)
-    try:
-        ncores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        ncores = os.cpu_count() or 1
+    # host threads for the CPU baseline and the input generation: the CPU share of this process (affinity capped by
+    # the cgroup quota), not the visible core count; must be set before the OpenMP library loads
+    from barcode_amd.inputs import host_cpu_share
+    ncores = host_cpu_share()
     os.environ.setdefault("OMP_NUM_THREADS", str(ncores))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 

@@ -188,6 +188,18 @@ static void hull_free(hull_t *u) {
  * ---------------------------------------------------------------------------------------------- */
 size_t orc_sizeof_config(void) { return sizeof(orc_config); }
 
+/* Thread count of the OpenMP build (no-op in the serial one).  The harness passes the host's CPU SHARE: on a GPU box
+ * whose cgroup grants 16 CPUs of 256 visible ones, 256 threads spin against the quota and a 64^3 step takes 18 s
+ * instead of 0.3 s. */
+#ifdef _OPENMP
+#include <omp.h>
+void orc_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
+int orc_get_max_threads(void) { return omp_get_max_threads(); }
+#else
+void orc_set_threads(int n) { (void)n; }
+int orc_get_max_threads(void) { return 1; }
+#endif
+
 int orc_create(const orc_config *cfg, orc_hamil **out) {
   if (!cfg || !out || cfg->N1 < 2 || !(cfg->L1 > 0)) return ORC_ERR_ARG;
   orc_hamil *h = (orc_hamil *)calloc(1, sizeof(orc_hamil));

@@ -58,6 +58,8 @@ enum { /* array slots for orc_set_array / orc_get_array */
 typedef struct orc_hamil orc_hamil;
 
 size_t orc_sizeof_config(void);
+void orc_set_threads(int n);    /* OpenMP build: omp_set_num_threads; serial build: no-op */
+int orc_get_max_threads(void);
 int orc_create(const orc_config *cfg, orc_hamil **out);
 void orc_destroy(orc_hamil *h);
 int orc_set_array(orc_hamil *h, int field, const double *src); /* copies N doubles in */

@@ -31,6 +31,31 @@ def test_config1_64cubed_ten_steps_against_oracle():
     e.close()
 
 
+@pytest.mark.parametrize("kw", [dict(likelihood=0, rsd_model=0), dict(likelihood=2, rsd_model=0),
+                                dict(likelihood=3, rsd_model=0), dict(likelihood=1, rsd_model=1, calc_h=3),
+                                dict(likelihood=1, rsd_model=0, sfmodel=2), dict(likelihood=1, rsd_model=1, mass_type=5)],
+                         ids=["poisson", "lognormal", "grf", "calc_h3_rsd", "alpt", "mass5_rsd"])
+def test_other_models_at_64_cubed_against_oracle(kw):
+    """The non-default likelihoods, the Fourier+TSC force, the ALPT forward model and a real-space mass at 64^3 (256
+    tiles, several work items per dense tile, planes mode for the default force path) instead of only at 16^3: a
+    5-step trajectory and the energies against the OpenMP oracle."""
+    from oracle.oracle import Oracle
+    c = Case(Nx=64, L=200.0, **kw)
+    c.oracle.close()
+    o = Oracle(c.p, omp=True)
+    o.set(**c.arrays())
+    e = c.engine()
+    q1o, p1o, done_o = o.Hamiltonian_EoM(c.q0, c.p0, c.eps, 5)
+    q1, p1, done = e.leapfrog(c.q0, c.p0, c.eps, 5)
+    assert done == done_o == 5
+    assert rel_l2(q1, q1o) < TOL_TRAJ_10 and rel_l2(p1, p1o) < TOL_TRAJ_10
+    dHo, to = o.delta_Hamiltonian(c.q0, c.p0, q1o, p1o)
+    dH, t = e.delta_hamiltonian(c.q0, c.p0, q1o, p1o)
+    assert np.all(np.abs(t - to) <= TOL_ENERGY * np.abs(to))
+    o.close()
+    e.close()
+
+
 def test_config2_128cubed_poisson_fifty_steps_against_oracle():
     """BASELINE config 2 at its real length: 128^3, Gaussian prior + Zel'dovich, Poissonian likelihood, 50 leapfrog
     steps, fp64 (HMC.cc:251-369).  Tolerance re-stated for 50 steps: TOL_TRAJ_50 (see tests/util.py: the measured
