@@ -107,6 +107,13 @@ int orc_alpt_displacement(orc_hamil *h, const double *in, double *psix, double *
 /* f-4: field_statistics.cpp:20-90 (FOURIER_DEF_2) */
 int orc_measure_spectrum(orc_hamil *h, const double *signal, double *kmode, double *power, uint64_t N_bin);
 
+/* oracle/orc_random.c: the reference's momentum draw with GSL's MT19937 + polar Box-Muller stream restated */
+int orc_create_GARFIELD(unsigned n, double L, const double *power, unsigned long seed, double *delta); /* random.cpp:48-511 */
+int orc_draw_momenta(unsigned n, double L, int mass_fs, int mass_rs, const double *mass_f, const double *mass_r,
+                     unsigned long seed, double *momenta);                                            /* HMC_momenta.cc:42-94 */
+void orc_mt19937_stream(unsigned long seed, uint32_t *out, size_t n);   /* gsl_rng_mt19937 raw outputs */
+void orc_ugaussian_stream(unsigned long seed, double *out, size_t n);   /* gsl_ran_ugaussian */
+
 double orc_fgrow(double a, double OM, double OL, int term);    /* cosmo.cc:182-217 */
 double orc_c_pecvel(double a, double OM, double OL, int term); /* cosmo.cc:220-235 */
 

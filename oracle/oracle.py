@@ -130,6 +130,14 @@ def _lib(omp):
         }.items():
             getattr(lib, name).argtypes = args
             getattr(lib, name).restype = C.c_int
+        lib.orc_create_GARFIELD.argtypes = [C.c_uint, C.c_double, dp, C.c_ulong, dp]
+        lib.orc_create_GARFIELD.restype = C.c_int
+        lib.orc_draw_momenta.argtypes = [C.c_uint, C.c_double, C.c_int, C.c_int, dp, dp, C.c_ulong, dp]
+        lib.orc_draw_momenta.restype = C.c_int
+        lib.orc_mt19937_stream.argtypes = [C.c_ulong, C.POINTER(C.c_uint32), C.c_size_t]
+        lib.orc_mt19937_stream.restype = None
+        lib.orc_ugaussian_stream.argtypes = [C.c_ulong, dp, C.c_size_t]
+        lib.orc_ugaussian_stream.restype = None
         lib.orc_overdens.argtypes = [vp, dp, dp]
         lib.orc_overdens.restype = None
         assert lib.orc_sizeof_config() == C.sizeof(OrcConfig)
@@ -352,3 +360,40 @@ class Oracle:
         self._chk(self.lib.orc_Hamiltonian_EoM(self.h, _p(self._in(qi)), _p(self._in(pi)), _p(qf), _p(pf),
                                                float(epsilon), int(Neps), C.byref(done)))
         return qf, pf, done.value
+
+
+# ---- the reference's momentum draw (oracle/orc_random.c; GSL's MT19937 + polar Box-Muller stream restated) ----
+def mt19937_stream(seed, n):
+    out = np.zeros(n, dtype=np.uint32)
+    _lib(False).orc_mt19937_stream(int(seed), out.ctypes.data_as(C.POINTER(C.c_uint32)), n)
+    return out
+
+
+def ugaussian_stream(seed, n):
+    out = np.zeros(n)
+    _lib(False).orc_ugaussian_stream(int(seed), _p(out), n)
+    return out
+
+
+def create_GARFIELD(n, L, power, seed):
+    """random.cpp:48-511: real Gaussian field with <|FFT|^2> = N^2 / V * power, from gsl_rng seed ``seed``."""
+    power = np.ascontiguousarray(power, dtype=np.float64).reshape(-1)
+    out = np.zeros(n ** 3)
+    rc = _lib(False).orc_create_GARFIELD(n, float(L), _p(power), int(seed), _p(out))
+    if rc:
+        raise OracleError(rc)
+    return out
+
+
+def draw_momenta(params, mass_f, mass_r, seed):
+    """HMC_momenta.cc:42-94 for the mass type of ``params``."""
+    mt = params.mass_type
+    fs, rs = int(mt in (1, 2, 3, 4, 5)), int(mt in (0, 5, 6, 60))
+    mf = None if mass_f is None else np.ascontiguousarray(mass_f, dtype=np.float64).reshape(-1)
+    mr = None if mass_r is None else np.ascontiguousarray(mass_r, dtype=np.float64).reshape(-1)
+    out = np.zeros(params.N)
+    rc = _lib(False).orc_draw_momenta(params.Nx, float(params.L), fs, rs, _p(mf) if mf is not None else None,
+                                      _p(mr) if mr is not None else None, int(seed), _p(out))
+    if rc:
+        raise OracleError(rc)
+    return out
