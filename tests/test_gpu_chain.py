@@ -107,17 +107,20 @@ def test_device_draw_has_the_spectrum_of_the_reference_draw():
     e.chain_set_state(c.q0)
     nbin = 24
     pw_dev, pw_ref = np.zeros(nbin), np.zeros(nbin)
-    for s in range(4):
+    for s in range(8):
         e.chain_draw_momenta(99, s)
         km, pw = e.measure_spectrum(e.chain_get_momenta(), nbin)
         pw_dev += pw
         km2, pw2 = e.measure_spectrum(orc.draw_momenta(c.p, c.mass_f, None, seed=1000 + s), nbin)
         pw_ref += pw2
     sel = (km > 0) & (pw_ref > 0)
-    assert np.count_nonzero(sel) >= 16
-    # shells with thousands of modes each: 4 realisations agree to a few per cent per bin, 1 % overall
-    assert np.all(np.abs(pw_dev[sel] / pw_ref[sel] - 1.0) < 0.15)
-    assert abs((pw_dev[sel] / pw_ref[sel])[4:].mean() - 1.0) < 0.02
+    assert np.count_nonzero(sel) >= 20
+    ratio = (pw_dev[sel] / pw_ref[sel])
+    # two independent sets of reference draws scatter by up to 20 % in the first bins and in the corner bins beyond the
+    # Nyquist sphere (few modes each) and by 1-3 % in between: the device draw must sit inside that band
+    assert np.all(np.abs(ratio - 1.0) < 0.35)
+    assert np.all(np.abs(ratio[6:20] - 1.0) < 0.08), ratio
+    assert abs(ratio[6:20].mean() - 1.0) < 0.02
     # and the reference draw itself goes through the engine unchanged
     pr = orc.draw_momenta(c.p, c.mass_f, None, seed=5)
     e.chain_set_momenta(pr)
