@@ -67,6 +67,31 @@ def main():
     print("acceptance %d/%d; resident-state spectrum bins with power: %d" % (n_acc, n_att, int((pw > 0).sum())))
     assert n_acc == 6 and np.isfinite(pw).all()
     hd.engine.close()
+    # ---- the C++ HamiltonianMC with the reference's step-size adaptation (scheme 3), from a step size 40x too large:
+    # the first sample halves eps_fac on every rejection (time_step.cpp:137-149), later samples adapt from the tables
+    from barcode_amd import time_step as ts
+    from barcode_amd.shim import ShimHamil
+    from tests.util import Case
+    c = Case(Nx=64, L=200.0, likelihood=1, rsd_model=1, sfmodel=2)
+    c.oracle.close()
+    sh = ShimHamil(c.p, N_eps_fac=8.0, eps_fac=40.0 * c.p.eps_heuristic(), **c.arrays())
+    sh.eps_attach(ts.EpsConfig(eps_fac_update_type=3, N_a_eps_update=20, acc_min=0.6, acc_max=0.7))
+    sh.chain_set_state(c.q0)
+    rng = np.random.default_rng(3)
+    tot = acc = 0
+    for sample in range(1, 41):
+        sh.numerical.iGibbs, sh.numerical.rejections = sample, 0
+        log = sh.HamiltonianMC(rng.random, seed=5, itmax=200)
+        tot += len(log)
+        acc += 1 if log[-1]["accepted"] else 0
+        if sample <= 3 or sample % 10 == 0:
+            print("C++ sample %2d: %2d attempt(s), eps_fac %.3e, table acceptance %.2f, records %d"
+                  % (sample, len(log), sh.numerical.eps_fac, sh.eps_acceptance_rate(), sh.eps_records()))
+        assert log[-1]["accepted"], "a sample ran to itmax"
+    print("C++ loop: %d samples in %d attempts (acceptance %.2f), final eps_fac / heuristic = %.2f"
+          % (acc, tot, acc / tot, sh.numerical.eps_fac / c.p.eps_heuristic()))
+    assert acc == 40 and sh.eps_records() == tot
+    sh.close()
 
 
 if __name__ == "__main__":
