@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--cpu-nx", type=int, default=0, help="grid of the CPU-baseline sample (default: same as --nx)")
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--fp32", action="store_true", help="fp32 field arrays (BASELINE config 5); tolerance re-stated")
+    ap.add_argument("--chains-per-gpu", type=int, default=1, choices=[1, 2],
+                    help="2: additionally measure the throughput mode -- two chains per GPU on disjoint halves of the "
+                         "CUs -- and report it as `throughput_mode` next to the headline (never instead of it)")
     ap.add_argument("--backend", default="nccl", help="process-group backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--exchange", default="torch", choices=["torch", "rccl"],
                     help="transport of the per-sample epsilon-record exchange behind bchmc_eps_exchange: torch.distributed "
@@ -145,6 +148,40 @@ def valu_roofline():
     d["source"] = os.path.relpath(paths[-1], ROOT)
     d["measured_in_run"] = False
     return d
+
+
+def two_chain_throughput(params, fields, arrays, dev, local_rank, eps, steps, precision):
+    """Throughput mode: two independent chains on ONE GPU, each handle's stream restricted to half of the CUs
+    (BCHMC_CU_MASK=lo / hi, hipExtStreamCreateWithCUMask), so that the VALU-bound particle-mesh kernels of one chain
+    run beside the HBM-bound transforms of the other.  Aggregate steps/s of both chains; per-chain latency doubles."""
+    import torch
+    from barcode_amd import inputs
+    from barcode_amd.engine import Engine
+    engines, states = [], []
+    for c, mask in enumerate(("lo", "hi")):
+        os.environ["BCHMC_CU_MASK"] = mask
+        e = Engine(params, device=local_rank, precision=precision)
+        e.upload(**arrays)
+        p0 = torch.from_numpy(inputs.gaussian_random_field(params, fields["mass_f"], inputs.SEED_P0 + 100 + c).reshape(-1)).to(dev)
+        q0 = torch.from_numpy(fields["q0"].reshape(-1)).to(dev)
+        engines.append(e)
+        states.append((q0, p0, torch.empty_like(q0), torch.empty_like(p0)))
+    os.environ.pop("BCHMC_CU_MASK", None)
+    for e, st in zip(engines, states):
+        e.leapfrog_device(*st, eps, 3)
+    for e in engines:
+        e.sync()
+    t0 = time.perf_counter()
+    for e, st in zip(engines, states):   # both trajectories are enqueued asynchronously, each on its own stream
+        e.leapfrog_device(*st, eps, steps)
+    done = [e.steps_done() for e in engines]   # synchronises each stream
+    dt = time.perf_counter() - t0
+    for e in engines:
+        e.close()
+    return dict(chains_per_gpu=2, value=round(2 * steps / dt, 4), unit="steps/s (aggregate of both chains)",
+                ms_per_step_per_chain=round(1e3 * dt / steps, 4), steps_done=[int(d) for d in done],
+                cu_masks=["lo", "hi"],
+                note="opt-in deployment mode for many-chain sampling; the headline `value` is one chain on the whole GPU")
 
 
 def launch_ranks(args):
@@ -296,6 +333,10 @@ def main():
                         bound="fp64 vector ALU + LDS atomics (DESIGN.md section 5), not HBM"
                         if dom in ("k_scatter_sph", "k_gather_sph") else "hbm")
 
+    throughput_mode = None
+    if args.chains_per_gpu == 2 and world == 1:
+        throughput_mode = two_chain_throughput(params, f, arrays, dev, local_rank, eps, args.steps, 1 if args.fp32 else 0)
+
     if rank == 0:
         N = params.N
         steps_total = args.steps * world
@@ -349,6 +390,8 @@ def main():
                 "valu": valu_roofline() if (rsd and params.likelihood == 1 and not args.fp32 and params.Nx == 256) else None,
             },
         }
+        if throughput_mode is not None:
+            out["throughput_mode"] = throughput_mode
         if world == 1 and not args.no_cpu_baseline:
             cpu_params = params
             cq0, cp0, carr = f["q0"], p0_host, arrays
