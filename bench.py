@@ -188,6 +188,11 @@ def launch_ranks(args):
     """Parent of a self-launched multi-GPU run: start one child per GPU, never touch the GPU here."""
     import socket
     import subprocess
+    import torch
+    ndev = torch.cuda.device_count()  # counting devices does not initialise the GPU runtime in this process
+    if args.gpus > ndev and not args.single_device:
+        print("bench.py: --gpus %d but this node shows %d GPU(s): refusing to run" % (args.gpus, ndev), file=sys.stderr)
+        sys.exit(2)
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
@@ -198,8 +203,22 @@ def launch_ranks(args):
                    BCHMC_BENCH_CHILD="1")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    # wait for all ranks; a rank that dies (no such device, out of memory, ...) leaves the others blocked in their
+    # rendezvous or barrier: end them (our own children, by PID) instead of waiting for a collective timeout
+    rcs = [None] * len(procs)
+    while any(rc is None for rc in rcs):
+        for i, pr in enumerate(procs):
+            if rcs[i] is None:
+                rcs[i] = pr.poll()
+        if any(rc not in (None, 0) for rc in rcs):
+            time.sleep(2.0)  # let the failing rank's message reach stderr first
+            for i, pr in enumerate(procs):
+                if rcs[i] is None:
+                    pr.kill()
+                    rcs[i] = pr.wait()
+            break
+        time.sleep(0.1)
+    out0 = procs[0].stdout.read()  # one JSON line: far below the pipe buffer, safe to read after the exit
     # exactly one JSON line on stdout: libraries of the children may have written their own chatter there
     for line in out0.decode().splitlines():
         if line.startswith("{"):
