@@ -274,8 +274,9 @@ def test_other_tilings_and_kernel_sizes(nx, kw):
 
 @pytest.mark.parametrize("cap", ["0", "8", "1100"], ids=["two_pass_only", "overflow_fallback", "tight_cap"])
 def test_tile_sort_fallback_paths(monkeypatch, cap):
-    """The one-pass tile binning reserves BCHMC_SORT_CAP record slots per tile (default 4x the mean occupancy); when a
-    tile overflows, or with the one-pass path disabled (0), the two-pass counting sort produces the records."""
+    """The one-pass tile binning reserves BCHMC_SORT_CAP record slots per tile (default 8x the mean occupancy, in eight
+    octant segments); when a segment overflows, or with the one-pass path disabled (0), the two-pass counting sort
+    produces the records and k_subsort orders them."""
     monkeypatch.setenv("BCHMC_SORT_CAP", cap)
     c = Case(Nx=16, likelihood=1, rsd_model=1)
     e = c.engine()
