@@ -666,7 +666,7 @@ struct Pipe {
       const int fb_grid = h->sort_direct ? std::min(nbricks, 4096) : nbricks;
       if (h->sort_direct) {
         const int nsuper = (nbricks + kBinPer - 1) / kBinPer;
-        k_bin_direct<T><<<nsuper, 256, 0, h->stream>>>(h->g, pp, sp, h->tp, nsuper, R(h->psi), cnt1, ovf,
+        k_bin_direct<T><<<nsuper, BCHMC_BIN_THREADS, 0, h->stream>>>(h->g, pp, sp, h->tp, nsuper, R(h->psi), cnt1, ovf,
                                                        (RecQuad *)h->srec, R(h->V), h->rho_part);
       } else {
         HIPCHK(hipMemsetAsync(ovf, 1, 1, h->stream));  // non-zero flag: two-pass sort only

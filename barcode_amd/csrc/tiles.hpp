@@ -127,8 +127,8 @@ __device__ __forceinline__ int tile_of_wrapped(const TilePar &tp, int cx, int cy
 
 // Workgroup -> particles.  When 16 divides n a workgroup takes a 4 x 4 x 16 brick of the Lagrangian lattice
 // (neighbours in space: few distinct tiles per workgroup, 128-byte rows of psi); otherwise 256 consecutive ones.
-__device__ __forceinline__ long long brick_particle(const Geo &g, int b, int &i, int &j, int &k) {
-  const int n = g.n, tid = threadIdx.x;
+__device__ __forceinline__ long long brick_particle(const Geo &g, int b, int tid, int &i, int &j, int &k) {
+  const int n = g.n;  // tid: 0..255 within the brick
   if ((n & 15) == 0) {
     const int nbz = n >> 4, nby = n >> 2;
     const int bk = b % nbz, bj = (b / nbz) % nby, bi = b / (nbz * nby);
@@ -137,12 +137,15 @@ __device__ __forceinline__ long long brick_particle(const Geo &g, int b, int &i,
     k = bk * 16 + (tid & 15);
     return k + (long long)n * (j + (long long)n * i);
   }
-  const long long p = b * (long long)blockDim.x + tid;
+  const long long p = b * 256ll + tid;
   k = (int)(p % n);
   const long long ij = p / n;
   j = (int)(ij % n);
   i = (int)(ij / n);
   return p;
+}
+__device__ __forceinline__ long long brick_particle(const Geo &g, int b, int &i, int &j, int &k) {
+  return brick_particle(g, b, (int)threadIdx.x, i, j, k);  // 256-thread workgroups
 }
 
 // Binning.  The workgroup first counts its particles per counter (tile, or tile and sub-cell octant) in an LDS hash
@@ -162,7 +165,12 @@ __device__ __forceinline__ long long brick_particle(const Geo &g, int b, int &i,
 #ifndef BCHMC_BIN_PER
 #define BCHMC_BIN_PER 4
 #endif
+#ifndef BCHMC_BIN_THREADS
+#define BCHMC_BIN_THREADS 256  // kBinPer bricks per hash table are handled by BCHMC_BIN_THREADS / 256 thread groups
+#endif
 constexpr int kBinPer = BCHMC_BIN_PER;
+constexpr int kBinGroups = BCHMC_BIN_THREADS / 256;   // bricks processed side by side
+constexpr int kBinLoop = kBinPer / kBinGroups;        // bricks per thread
 
 // brick m of super-brick sb: a PI x PJ group in (i, j) when the bricks are 4 x 4 x 16 (kBinPer = 1, 2 or 4), else
 // kBinPer consecutive ones
@@ -179,7 +187,7 @@ __device__ __forceinline__ int super_brick(const Geo &g, int sb, int m) {
 }
 
 template <typename T>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(BCHMC_BIN_THREADS)
 k_bin_direct(Geo g, PosPar pp, SphPar sp, TilePar tp, int nsuper, const T *__restrict__ psi, int *__restrict__ cnt,
              int *__restrict__ ovf, RecQuad *__restrict__ srec, T *__restrict__ V, double *__restrict__ zero_part) {
   constexpr int kSlots = 2048;  // > kBinPer * 256 distinct counters can never occur: the probing always terminates
@@ -194,13 +202,14 @@ k_bin_direct(Geo g, PosPar pp, SphPar sp, TilePar tp, int nsuper, const T *__res
       hcnt[s] = 0;
     }
     __syncthreads();
-    long long p[kBinPer];
-    int key[kBinPer], slot[kBinPer], local[kBinPer], flag[kBinPer];
-    T x[kBinPer], y[kBinPer], z[kBinPer];
+    long long p[kBinLoop];
+    int key[kBinLoop], slot[kBinLoop], local[kBinLoop], flag[kBinLoop];
+    T x[kBinLoop], y[kBinLoop], z[kBinLoop];
+    const int tid = (int)threadIdx.x & 255, grp = (int)threadIdx.x >> 8;
 #pragma unroll
-    for (int m = 0; m < kBinPer; m++) {
+    for (int m = 0; m < kBinLoop; m++) {
       int i, j, k;
-      p[m] = brick_particle(g, super_brick(g, sb, m), i, j, k);
+      p[m] = brick_particle(g, super_brick(g, sb, m * kBinGroups + grp), tid, i, j, k);
       key[m] = -1;
       slot[m] = local[m] = flag[m] = 0;
       x[m] = y[m] = z[m] = T(0);
@@ -231,7 +240,7 @@ k_bin_direct(Geo g, PosPar pp, SphPar sp, TilePar tp, int nsuper, const T *__res
     __syncthreads();
     const int seg = tp.cap / kOct;
 #pragma unroll
-    for (int m = 0; m < kBinPer; m++) {
+    for (int m = 0; m < kBinLoop; m++) {
       if (key[m] < 0) continue;
       const int rank = hbase[slot[m]] + local[m];
       if (rank >= seg) {
