@@ -706,22 +706,22 @@ struct Pipe {
         if (h->std81) {
           if (h->fix)
             k_scatter_tile81<T, 12, 20, true><<<grid, 256, tile_lds(h, 0, sizeof(double)), h->stream>>>(
-                h->g, sp, h->tp, reorder, (RecQuad *)h->srec, h->t_off, h->t_end, h->t_woff,
+                h->g, sp, h->tp, (const RecQuad *)h->srec, h->t_off, h->t_end, h->t_woff,
                 h->t_oct, h->t_seg, h->rho_fix, h->rho_part, h->t_cnt,
                 (kOct + 1) * h->tp.ntiles + 1, fix_scale);
           else
             k_scatter_tile81<T, 12, 20, false><<<grid, 256, tile_lds(h, 0, sizeof(double)), h->stream>>>(
-                h->g, sp, h->tp, reorder, (RecQuad *)h->srec, h->t_off, h->t_end, h->t_woff,
+                h->g, sp, h->tp, (const RecQuad *)h->srec, h->t_off, h->t_end, h->t_woff,
                 h->t_oct, h->t_seg, R(h->rho), h->rho_part, h->t_cnt,
                 (kOct + 1) * h->tp.ntiles + 1, fix_scale);
           h->cnt_clean = true;
         } else if (h->fix) {
           k_scatter_tile<T, true><<<grid, 256, tile_lds(h, ncol, sizeof(double)), h->stream>>>(
-              h->g, sp, h->tp, h->hull, ncol, reorder, (RecQuad *)h->srec, h->t_off, h->t_end,
+              h->g, sp, h->tp, h->hull, ncol, (const RecQuad *)h->srec, h->t_off, h->t_end,
               h->t_woff, h->t_oct, h->t_seg, h->rho_fix, h->rho_part, fix_scale);
         } else {
           k_scatter_tile<T, false><<<grid, 256, tile_lds(h, ncol, sizeof(double)), h->stream>>>(
-              h->g, sp, h->tp, h->hull, ncol, reorder, (RecQuad *)h->srec, h->t_off, h->t_end,
+              h->g, sp, h->tp, h->hull, ncol, (const RecQuad *)h->srec, h->t_off, h->t_end,
               h->t_woff, h->t_oct, h->t_seg, R(h->rho), h->rho_part, fix_scale);
         }
       } else if (h->c.mk == 3) {

@@ -568,7 +568,7 @@ __device__ __forceinline__ double flush_cell(long long *dst, long long v) {
 // getDensity_SPH on sorted particles: LDS accumulation per (tile, chunk), one flush.
 template <typename T, bool FIX>
 __global__ void __launch_bounds__(256)
-k_scatter_tile(Geo g, SphPar sp, TilePar tp, const int4 *__restrict__ cols, int ncol, int reorder, RecQuad *srec,
+k_scatter_tile(Geo g, SphPar sp, TilePar tp, const int4 *__restrict__ cols, int ncol, const RecQuad *__restrict__ srec,
                const long long *__restrict__ off, const long long *__restrict__ tend, const int *__restrict__ woff,
                const int4 *__restrict__ oct, const int *__restrict__ seg_in,
                typename Cell<FIX, T>::type *__restrict__ rho, double *__restrict__ rho_part, double fix_scale) {
@@ -756,7 +756,7 @@ __host__ __device__ constexpr int hull81_zw(int a, int b) {
 #endif
 template <typename T, int LY, int LZ, bool FIX>
 __global__ void __launch_bounds__(256, BCHMC_SCATTER_WAVES)
-k_scatter_tile81(Geo g, SphPar sp, TilePar tp, int reorder, RecQuad *srec,
+k_scatter_tile81(Geo g, SphPar sp, TilePar tp, const RecQuad *__restrict__ srec,
                  const long long *__restrict__ off, const long long *__restrict__ tend, const int *__restrict__ woff,
                  const int4 *__restrict__ oct, const int *__restrict__ seg_in,
                  typename Cell<FIX, T>::type *__restrict__ rho, double *__restrict__ rho_part, int *__restrict__ cnt_zero,
