@@ -207,7 +207,8 @@ typedef int (*bchmc_allgather_fn)(void *ctx, const void *send, void *recv, size_
 /* RCCL transport: rank 0 calls bchmc_comm_unique_id and hands the 128 bytes to the other ranks (a file, an
  * environment variable, MPI_Bcast: the shim's bootstrap helper uses a file), then every rank
  * calls bchmc_comm_create: ncclCommInitRank on `device`, a side stream and a 2 x world x 520-byte staging buffer.
- * librccl is loaded on first use (dlopen), so single-chain runs do not depend on it. */
+ * librccl is loaded on first use (dlopen), so single-chain runs do not depend on it.  On failure *out still holds an
+ * object (bchmc_comm_last_error tells why); release it with bchmc_comm_destroy like a working one. */
 int bchmc_comm_unique_id(unsigned char id[BCHMC_UNIQUE_ID_BYTES]);
 int bchmc_comm_create(const unsigned char id[BCHMC_UNIQUE_ID_BYTES], int rank, int world, int device, bchmc_comm **out);
 int bchmc_comm_create_custom(bchmc_allgather_fn fn, void *ctx, int rank, int world, bchmc_comm **out);
