@@ -96,24 +96,28 @@ def big():
     e.close()
 
 
-def test_config3_256cubed_three_steps_and_energies_against_oracle(big):
+def test_config3_256cubed_eight_steps_and_energies_against_oracle(big):
     """BASELINE config 3 at the benchmarked size, against the oracle (OpenMP build, ~20 s of host time): the
     instantiations bench.py times -- k_step_boundary_x<double, 512, 4>, chunk = 2048, padded rows nhp = 136, 16384
-    tiles with 64-bit record offsets -- on a 3-step trajectory (first step: 3-D plans, interior: planes mode, last:
-    3-D plans; HMC.cc:251-369) and delta_Hamiltonian (HMC.cc:209-248)."""
+    tiles with 64-bit record offsets -- on an 8-step trajectory (first step: 3-D plans, six interior steps in planes
+    mode, last: 3-D plans; HMC.cc:251-369; 8 = the reference's largest default Neps, HMC.cc:260) and delta_Hamiltonian
+    (HMC.cc:209-248)."""
     from oracle.oracle import Oracle
     p, f, e, dX = big
     window, noise, nobs = inputs.mock_observations(p, dX)
     o = Oracle(p, omp=True)
     o.set(signal_PS=f["signal_PS"], mass_f=f["mass_f"], window=window, noise=noise, nobs=nobs)
     eps = 0.5 * p.eps_heuristic()  # the bench's step size
-    q1o, p1o, done_o = o.Hamiltonian_EoM(f["q0"], f["p0"], eps, 3)
-    q1, p1, done = e.leapfrog(f["q0"], f["p0"], eps, 3)
-    assert done == done_o == 3
+    q1o, p1o, done_o = o.Hamiltonian_EoM(f["q0"], f["p0"], eps, 8)
+    q1, p1, done = e.leapfrog(f["q0"], f["p0"], eps, 8)
+    assert done == done_o == 8
     assert rel_l2(q1, q1o) < TOL_TRAJ_10 and rel_l2(p1, p1o) < TOL_TRAJ_10
     dHo, to = o.delta_Hamiltonian(f["q0"], f["p0"], q1o, p1o)
     dH, t = e.delta_hamiltonian(f["q0"], f["p0"], q1o, p1o)
     assert np.all(np.abs(t - to) <= TOL_ENERGY * np.abs(to))
+    # the host-array pair as HamiltonianMC issues it (energies taken from the trajectory's own pass)
+    dH2, t2 = e.delta_hamiltonian(f["q0"], f["p0"], q1, p1)
+    assert np.all(np.abs(t2 - to) <= 10 * TOL_ENERGY * np.abs(to))
     # the force itself and the forward model's density at this size
     g = e.gradient(f["q0"])
     g_o = o.gradient_psi(f["q0"])[0]
