@@ -156,3 +156,14 @@ def test_cpp_host_layer_is_built_and_exports_its_hooks():
         assert hasattr(lib, s)
     assert lib.bchmc_shim_sizeof_view() == C.sizeof(shim.HamilView)
     assert lib.bchmc_shim_sizeof_numerical() == C.sizeof(shim.HamilNumericalView)
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """`python bench.py --gpus N` starts its own ranks; with fewer GPUs than ranks (none in the build container) it must
+    refuse with a non-zero exit code instead of recording an N-GPU number from fewer chains, and never touch a GPU in
+    the parent (torch.cuda.device_count() only)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300,
+                       env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    assert r.returncode == 2
+    assert b"refusing to run" in r.stderr and r.stdout.strip() == b""
