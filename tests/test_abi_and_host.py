@@ -162,6 +162,9 @@ def test_bench_refuses_more_ranks_than_gpus():
     """`python bench.py --gpus N` starts its own ranks; with fewer GPUs than ranks (none in the build container) it must
     refuse with a non-zero exit code instead of recording an N-GPU number from fewer chains, and never touch a GPU in
     the parent (torch.cuda.device_count() only)."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this machine could actually run two ranks")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300,
                        env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
