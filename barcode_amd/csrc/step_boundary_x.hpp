@@ -3,6 +3,9 @@
 #pragma once
 #include "common.hpp"
 
+#ifndef BCHMC_BX_WAVES
+#define BCHMC_BX_WAVES 4
+#endif
 namespace bchmc {
 
 // ======================================================================================================
@@ -93,7 +96,7 @@ __device__ __forceinline__ void xfft_inplace(C2<T> *__restrict__ s, const C2<T> 
 }
 
 template <typename T, int NT, int PER>
-__global__ void __launch_bounds__(NT, 4)
+__global__ void __launch_bounds__(NT, BCHMC_BX_WAVES)
 k_step_boundary_x(Geo g, int log2n, const C2<T> *__restrict__ twiddle, C2<T> *Ck, const C2<T> *q_in, const C2<T> *p_in,
                   C2<T> *q_out, C2<T> *p_out, const double *__restrict__ wS, const double *__restrict__ wM, double a,
                   double b, double half_eps, double eps, double c_za, double *guard_slot, StepCtl ctl) {
