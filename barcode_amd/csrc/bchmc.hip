@@ -78,6 +78,12 @@ struct bchmc_handle {
   void *cq = nullptr, *cp = nullptr;                 // Nhp complex each
   double *part6 = nullptr;                           // 6 * kRedBlocks doubles
   bool have_cq = false, have_cp = false, have_prop = false;
+  // Force carried along the chain: g^ = FFT-space gradient_psi at the chain state cq, with its -log L.  The end of an
+  // accepted trajectory (or the start of a rejected one) IS the next trajectory's start, so the gradient HMC.cc:279
+  // evaluates there is already known; only the fast attempt mode uses it.  Any new input or state invalidates it.
+  void *cg = nullptr;
+  bool cg_valid = false, prop_g_valid = false;
+  double c_like = 0., prop_like = 0.;
   double *rho_part = nullptr, *partA = nullptr;      // kRedBlocks doubles each
   double *guard = nullptr;                           // guard slots, one per step
   size_t guard_cap = 0;
@@ -543,6 +549,7 @@ struct Pipe {
 
   static T *R(void *p) { return reinterpret_cast<T *>(p); }
   static CT *C(void *p) { return reinterpret_cast<CT *>(p); }
+  static const CT *C(const void *p) { return reinterpret_cast<const CT *>(p); }
 
   static size_t tile_lds(const bchmc_handle *h, int ncol, size_t cell_bytes) {
     const size_t ncell = (size_t)h->tp.lx * h->tp.ly * h->tp.lz;
@@ -895,6 +902,7 @@ struct Pipe {
 
   template <bool KICK>
   static int launch_assemble(bchmc_handle *h, double a, double b, int like_mode, double c_kick, double *guard_slot) {
+    h->prop_g_valid = false;  // gk is rewritten: whatever gradient a chain proposal left there is gone
     ProfScope ps(h, BCHMC_K_KSPACE_FORCE_KICK);
     k_assemble<T, KICK><<<nblk_stride(h->g.Nhp), 256, 0, h->stream>>>(h->g, C(h->Ck), C(h->qk), h->wS, C(h->gk), C(h->pk),
                                                                      a, b, like_mode, c_kick, guard_slot, h->stop);
@@ -954,7 +962,11 @@ struct Pipe {
   }
 
   // Hamiltonian_EoM (HMC.cc:275-365) on the k-space state already in (qk, pk).
-  static int trajectory(bchmc_handle *h, double eps, uint64_t neps, const Tap *tap) {
+  // g0_in: the gradient at the start state if the caller has it (the evaluation of HMC.cc:279 is skipped);
+  // g0_out: where to keep a copy of it when it is evaluated here.
+  static int trajectory(bchmc_handle *h, double eps, uint64_t neps, const Tap *tap, const void *g0_in = nullptr,
+                        void *g0_out = nullptr) {
+    h->prop_g_valid = false;
     CHK(grow_sort_slots(h));
     if (neps + 1 > h->guard_cap) {
       if (h->guard) (void)hipFree(h->guard);
@@ -970,29 +982,36 @@ struct Pipe {
     int like_mode = 2;
     double b = 0.;
     // 0) gradient at t = 0 (HMC.cc:279-280)
-    CHK(force_sources(h, false, &like_mode, &b));
-    if (tap && tap->like_i) CHK(tap_loglike(h, tap->like_i));
-    CHK(launch_assemble<false>(h, a, b, like_mode, 0., nullptr));
+    if (!g0_in) {
+      CHK(force_sources(h, false, &like_mode, &b));
+      if (tap && tap->like_i) CHK(tap_loglike(h, tap->like_i));
+      CHK(launch_assemble<false>(h, a, b, like_mode, 0., nullptr));
+      if (g0_out)
+        HIPCHK(hipMemcpyAsync(g0_out, h->gk, 2 * (size_t)h->g.Nhp * sizeof(T), hipMemcpyDeviceToDevice, h->stream));
+    }
+    const void *g_first = g0_in ? g0_in : h->gk;
 
     // the k-space kernels produce the Zel'dovich Psi^ as a by-product; the ALPT model needs its own pipeline
     const bool fused_za = (h->c.likelihood != 3) && !uses_alpt(h, h->c.rsd_model);
     const double *wM = h->mass_fs ? h->wM : nullptr;
     const double c_za = -h->c.D1 * h->c.deltaQ_factor / (double)h->g.N;
     const double guard_limit = 1e50 * (double)h->g.N;
-    if (fused_za && !h->mass_rs && !env_on("BCHMC_NO_FUSE")) return trajectory_fused(h, eps, neps, tap, a, wM, c_za);
+    if (fused_za && !h->mass_rs && !env_on("BCHMC_NO_FUSE"))
+      return trajectory_fused(h, eps, neps, tap, a, wM, c_za, g_first);
     for (uint64_t s = 0; s < neps; s++) {
       StepCtl ctl{h->stop, h->steps_done, s > 0 ? h->guard + (s - 1) : nullptr, guard_limit, s};
       if (!h->mass_rs) {
         ProfScope ps(h, BCHMC_K_KSPACE_DRIFT_ZA);
-        k_kick_drift_za<T, true><<<nblk_stride(h->g.Nhp), 256, 0, h->stream>>>(h->g, C(h->qk), C(h->pk), C(h->gk), wM,
-                                                                             nullptr, C(h->Ck), 0.5 * eps, eps, c_za, ctl);
+        k_kick_drift_za<T, true><<<nblk_stride(h->g.Nhp), 256, 0, h->stream>>>(
+            h->g, C(h->qk), C(h->pk), C(s == 0 ? g_first : h->gk), wM, nullptr, C(h->Ck), 0.5 * eps, eps, c_za, ctl);
         HIPCHK(hipGetLastError());
       } else {
         // kick first (needs p in real space for the mass_r term), then drift with the extra term
         {
           ProfScope ps(h, BCHMC_K_KSPACE_DRIFT_ZA);
           k_kick_drift_za<T, true><<<nblk_stride(h->g.Nhp), 256, 0, h->stream>>>(
-              h->g, C(h->qk), C(h->pk), C(h->gk), nullptr, nullptr, C(h->Ck), 0.5 * eps, 0., c_za, ctl);
+              h->g, C(h->qk), C(h->pk), C(s == 0 ? g_first : h->gk), nullptr, nullptr, C(h->Ck), 0.5 * eps, 0., c_za,
+              ctl);
           HIPCHK(hipGetLastError());
         }
         CHK(mass_rs_term(h));
@@ -1042,7 +1061,7 @@ struct Pipe {
   // The same trajectory with every interior "second half kick | first half kick + drift + Zel'dovich" pair done by
   // one kernel (k_step_boundary) on ping-pong state buffers.  Used for k-space masses and forward-model likelihoods.
   static int trajectory_fused(bchmc_handle *h, double eps, uint64_t neps, const Tap *tap, double a, const double *wM,
-                              double c_za) {
+                              double c_za, const void *g_first) {
     const double guard_limit = 1e50 * (double)h->g.N;
     if (!h->qk2) {
       CHK(dev_alloc_bytes(h, &h->qk2, 2 * (size_t)h->g.Nhp * sizeof(T)));
@@ -1055,7 +1074,7 @@ struct Pipe {
     {
       StepCtl ctl{h->stop, h->steps_done, nullptr, guard_limit, 0};
       ProfScope ps(h, BCHMC_K_KSPACE_DRIFT_ZA);
-      k_kick_drift_za<T, true><<<nblk_stride(h->g.Nhp), 256, 0, h->stream>>>(h->g, C(q0), C(p0), C(h->gk), wM, nullptr,
+      k_kick_drift_za<T, true><<<nblk_stride(h->g.Nhp), 256, 0, h->stream>>>(h->g, C(q0), C(p0), C(g_first), wM, nullptr,
                                                                            C(h->Ck), 0.5 * eps, eps, c_za, ctl);
       HIPCHK(hipGetLastError());
     }
@@ -1162,8 +1181,11 @@ struct Pipe {
   // generic mode -> (d_q0, d_p0), ABI doubles in real space, optionally with the exact k-space state to restart from
   // in (src_qk, src_pk).  The proposal stays in (qk, pk); with want_real the generic mode's real-space copy of it is
   // left in dstage (fast mode: the caller transforms).
+  // Fast mode only: g0_in / like0 = the gradient and -log L at the start state when the caller carries them;
+  // g0_out = where to keep the gradient at the start state otherwise.
   static int attempt_core(bchmc_handle *h, double eps, uint64_t neps, const double *d_q0, const double *d_p0,
-                          const void *src_qk, const void *src_pk, double terms[6], uint64_t *steps_done) {
+                          const void *src_qk, const void *src_pk, double terms[6], uint64_t *steps_done,
+                          const void *g0_in = nullptr, double like0 = 0., void *g0_out = nullptr) {
     CHK(check_inputs(h));
     if (eps > 2.) eps = 2.;
     const size_t cbytes = 2 * (size_t)h->g.Nhp * sizeof(T);
@@ -1182,8 +1204,9 @@ struct Pipe {
       k_parseval<T><<<kRedBlocks, 256, 0, h->stream>>>(h->g, C(h->qk), h->wS, P + kRedBlocks);
       HIPCHK(hipGetLastError());
     }
-    Tap tap{P + 2 * kRedBlocks, P + 5 * kRedBlocks};
-    CHK(trajectory(h, eps, neps, fast ? &tap : nullptr));
+    Tap tap{g0_in ? nullptr : P + 2 * kRedBlocks, P + 5 * kRedBlocks};
+    if (g0_in) HIPCHK(hipMemsetAsync(P + 2 * kRedBlocks, 0, kRedBlocks * sizeof(double), h->stream));
+    CHK(trajectory(h, eps, neps, fast ? &tap : nullptr, fast ? g0_in : nullptr, fast ? g0_out : nullptr));
     uint64_t done = 0;
     if (fast) {
       k_parseval<T><<<kRedBlocks, 256, 0, h->stream>>>(h->g, C(h->pk), h->wM, P + 3 * kRedBlocks);
@@ -1199,6 +1222,7 @@ struct Pipe {
         for (int i = 0; i < kRedBlocks; i++) s += hp[(size_t)t * kRedBlocks + i];
         terms[t] = (t == 0 || t == 1 || t == 3 || t == 4) ? s / (2. * N) : s;
       }
+      if (g0_in) terms[2] = like0;
       if (done < neps) {
         // runaway guard fired (HMC.cc:360-364): the tapped forward model is not the final state's; redo it
         CHK(displacement(h, h->c.likelihood == 1 ? h->c.deltaQ_factor : 1., h->c.likelihood == 1 ? h->c.rsd_model : 0));
@@ -1225,8 +1249,21 @@ struct Pipe {
     if (attempt_is_fast(h, neps)) {
       HIPCHK(hipMemcpyAsync(h->qk, h->cq, cbytes, hipMemcpyDeviceToDevice, h->stream));
       HIPCHK(hipMemcpyAsync(h->pk, h->cp, cbytes, hipMemcpyDeviceToDevice, h->stream));
-      CHK(attempt_core(h, eps, neps, nullptr, nullptr, nullptr, nullptr, terms, steps_done));
+      const bool use = !env_on("BCHMC_NO_FORCE_CARRY"), carry = use && h->cg_valid;
+      if (use && !h->cg) CHK(dev_alloc_bytes(h, &h->cg, cbytes));
+      uint64_t done = 0;
+      CHK(attempt_core(h, eps, neps, nullptr, nullptr, nullptr, nullptr, terms, &done, carry ? h->cg : nullptr,
+                       h->c_like, (use && !carry) ? h->cg : nullptr));
+      if (steps_done) *steps_done = done;
+      if (use && !carry) {
+        h->cg_valid = true;
+        h->c_like = terms[2];
+      }
+      // gk holds the gradient at the proposal (the last step's evaluation) unless the runaway guard cut the trajectory
+      h->prop_g_valid = use && done == neps;
+      h->prop_like = terms[5];
     } else {
+      h->cg_valid = h->prop_g_valid = false;
       CHK(c2r_state(h, h->cq, h->ioq, h->dstage));
       CHK(c2r_state(h, h->cp, h->iop, h->dstage + h->g.N));
       CHK(attempt_core(h, eps, neps, h->dstage, h->dstage + h->g.N, h->cq, h->cp, terms, steps_done));
@@ -1750,7 +1787,7 @@ void bchmc_destroy(bchmc_handle *h) {
   if (h->info) rocfft_execution_info_destroy(h->info);
   void *ptrs[] = {h->work,  h->wS,       h->wM,    h->qk,    h->pk,   h->gk,     h->Ck,         h->tC,   h->psi,
                   h->V,     h->rho,      h->plike, h->ioq,   h->iop,  h->gprior, h->glike,      h->conv, h->convF,
-                  h->dstage, h->rho_fix, h->spec_bins, h->cq, h->cp, h->qk2, h->pk2, h->xtw, h->part6, h->rho_part, h->partA, h->guard, h->stop, h->steps_done, h->hull,  h->t_cnt, h->t_off,
+                  h->dstage, h->rho_fix, h->spec_bins, h->cq, h->cp, h->cg, h->qk2, h->pk2, h->xtw, h->part6, h->rho_part, h->partA, h->guard, h->stop, h->steps_done, h->hull,  h->t_cnt, h->t_off,
                   h->t_woff, h->t_oct, h->t_seg, h->t_end, h->t_rank,  h->srec};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
@@ -1778,6 +1815,7 @@ int bchmc_upload(bchmc_handle *h, bchmc_field field, const double *host, size_t 
   CHK(DISPATCH(h, upload(h, field, h->dstage)));
   HIPCHK(hipStreamSynchronize(h->stream));
   h->have[field] = true;
+  h->cg_valid = h->prop_g_valid = false;  // the carried gradient belonged to the old inputs
   return BCHMC_OK;
 }
 
@@ -1948,6 +1986,7 @@ int bchmc_chain_set_state(bchmc_handle *h, const double *q) {
   HIPCHK(hipStreamSynchronize(h->stream));
   h->have_cq = true;
   h->have_prop = false;
+  h->cg_valid = h->prop_g_valid = false;
   return BCHMC_OK;
 }
 
@@ -2021,7 +2060,15 @@ int bchmc_chain_accept(bchmc_handle *h, int accepted) {
   if (accepted) {  // HMC.cc:497-498: copyArray(signalf, hd->x)
     HIPCHK(hipMemcpyAsync(h->cq, h->qk, 2 * (size_t)h->g.Nhp * h->esz, hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->prop_g_valid) {  // the proposal's gradient and -log L become the chain state's
+      std::swap(h->gk, h->cg);
+      h->c_like = h->prop_like;
+      h->cg_valid = true;
+    } else {
+      h->cg_valid = false;
+    }
   }
+  h->prop_g_valid = false;
   h->have_prop = false;
   return BCHMC_OK;
 }

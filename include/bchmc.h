@@ -160,7 +160,11 @@ int bchmc_chain_get_momenta(bchmc_handle *h, double *p);
 /* p ~ N(0, M) on the device: counter-based Philox4x32-10, a pure function of (seed, attempt, cell).  Statistical
  * stand-in for draw_momenta (HMC_momenta.cc:42-94), whose serial GSL stream it does not reproduce. */
 int bchmc_chain_draw_momenta(bchmc_handle *h, uint64_t seed, uint64_t attempt);
-/* Hamiltonian_EoM + delta_Hamiltonian from the resident (q, p); terms as in bchmc_delta_hamiltonian. */
+/* Hamiltonian_EoM + delta_Hamiltonian from the resident (q, p); terms as in bchmc_delta_hamiltonian.
+ * The chain carries gradient_psi and -log L of its state from one attempt to the next: the last force evaluation of an
+ * accepted trajectory (HMC.cc:349) is at the point where the next one starts, and a rejected attempt restarts from the
+ * same point, so the evaluation of HMC.cc:279 is skipped from the second attempt on (same numbers to round-off;
+ * bchmc_upload and bchmc_chain_set_state drop the carried values).  BCHMC_NO_FORCE_CARRY=1 re-evaluates every time. */
 int bchmc_chain_attempt(bchmc_handle *h, double eps, uint64_t neps, double *dH, double terms[6], uint64_t *steps_done);
 int bchmc_chain_get_proposal(bchmc_handle *h, double *q1, double *p1);
 int bchmc_chain_accept(bchmc_handle *h, int accepted);         /* accepted: q := proposal (HMC.cc:497-498) */

@@ -33,10 +33,10 @@ def host_path():
     return e.delta_hamiltonian(q0, p0, q1, p1)[0]
 
 
-def chain_path(i):
+def chain_path(i, accept=False):
     e.chain_draw_momenta(1, i)
     dH, _, _ = e.chain_attempt(eps, neps)
-    e.chain_accept(False)
+    e.chain_accept(accept)
     return dH
 
 
@@ -52,6 +52,16 @@ for i in range(reps):
     chain_path(i + 1)
 t2 = time.perf_counter()
 import os  # noqa: E402
+# the same chain with every proposal accepted (the carried gradient is the proposal's), and without carrying it
+for i in range(reps):
+    chain_path(100 + i, True)
+t2a = time.perf_counter()
+os.environ["BCHMC_NO_FORCE_CARRY"] = "1"
+chain_path(200)
+t2b = time.perf_counter()
+for i in range(reps):
+    chain_path(201 + i, True)
+t2c = time.perf_counter()
 os.environ["BCHMC_NO_DH_CACHE"] = "1"   # the r01 protocol: plain trajectory, then two full energy evaluations
 host_path()
 t3 = time.perf_counter()
@@ -60,6 +70,8 @@ for _ in range(reps):
 t4 = time.perf_counter()
 print(json.dumps(dict(grid=nx, neps=neps, host_array_ms_per_attempt=1e3 * (t1 - t0) / reps,
                       resident_chain_ms_per_attempt=1e3 * (t2 - t1) / reps,
+                      resident_chain_all_accepted_ms=1e3 * (t2a - t2) / reps,
+                      resident_chain_gradient_recomputed_ms=1e3 * (t2c - t2b) / reps,
                       host_array_without_trajectory_reuse_ms=1e3 * (t4 - t3) / reps,
                       note="host path = bchmc_leapfrog + bchmc_delta_hamiltonian on caller arrays (pinned staging, "
                            "energies taken from the trajectory's own pass); excludes the host-side momentum draw the "

@@ -49,6 +49,59 @@ def test_attempt_equals_leapfrog_plus_delta_hamiltonian(kw):
     e.close()
 
 
+@pytest.mark.parametrize("kw", [dict(likelihood=1, rsd_model=1), dict(likelihood=0)], ids=["gauss_rsd", "poisson"])
+def test_gradient_carried_across_attempts(kw, monkeypatch):
+    """The chain keeps gradient_psi and -log L of its state from one attempt to the next (the end of an accepted
+    trajectory, or the start of a rejected one, is the next start: the evaluation of HMC.cc:279 is already known).
+    Every attempt of an accept / reject sequence must still equal Hamiltonian_EoM + delta_Hamiltonian of the oracle
+    from the same state, the carried chain must equal the recomputing one, and new inputs must drop the carry."""
+    c = Case(Nx=16, **kw)
+    rng = np.random.default_rng(5)
+    pattern = [True, False, False, True, True]
+    moms = [c.p0 * (1. + 0.1 * rng.standard_normal()) for _ in pattern]
+
+    def run(engine):
+        out = []
+        engine.chain_set_state(c.q0)
+        for acc, p in zip(pattern, moms):
+            engine.chain_set_momenta(p)
+            dH, terms, done = engine.chain_attempt(c.eps, 3)
+            out.append((dH, terms.copy(), engine.chain_get_proposal()[0]))
+            engine.chain_accept(acc)
+        return out
+
+    e = c.engine()
+    carried = run(e)
+    monkeypatch.setenv("BCHMC_NO_FORCE_CARRY", "1")
+    recomputed = run(e)
+    monkeypatch.delenv("BCHMC_NO_FORCE_CARRY")
+    q = c.q0
+    for acc, p, (dH, terms, q1), (dH2, terms2, q12) in zip(pattern, moms, carried, recomputed):
+        q1o, p1o, _ = c.oracle.Hamiltonian_EoM(q, p, c.eps, 3)
+        dHo, to = c.oracle.delta_Hamiltonian(q, p, q1o, p1o)
+        assert rel_l2(q1, q1o) < TOL_TRAJ_10 and rel_l2(q12, q1o) < TOL_TRAJ_10
+        assert np.all(np.abs(terms - to) <= 10 * TOL_ENERGY * np.abs(to)), (terms, to)
+        assert np.all(np.abs(terms - terms2) <= 10 * TOL_ENERGY * np.abs(to))
+        assert abs(dH - dHo) <= 1e-9 * np.abs(to).max() and abs(dH - dH2) <= 1e-9 * np.abs(to).max()
+        if acc:
+            q = q1o
+    # new data: the next attempt must see it (same answer as an engine that never carried anything)
+    nobs2 = c.nobs * 1.25 + 0.5
+    e.upload(nobs=nobs2)
+    e.chain_set_momenta(moms[0])
+    dH_new, terms_new, _ = e.chain_attempt(c.eps, 3)
+    e.close()
+    c2 = Case(Nx=16, **kw)
+    e2 = c2.engine()
+    e2.upload(nobs=nobs2)
+    e2.chain_set_state(q)
+    e2.chain_set_momenta(moms[0])
+    dH_ref, terms_ref, _ = e2.chain_attempt(c.eps, 3)
+    e2.close()
+    assert np.all(np.abs(terms_new - terms_ref) <= 1e-9 * np.abs(terms_ref)), (terms_new, terms_ref)
+    assert abs(terms_new[2] - carried[-1][1][5]) > 1e-6 * abs(terms_new[2])  # and it is not the stale -log L
+
+
 def test_attempt_after_runaway_guard():
     c = Case(Nx=16)
     e = c.engine()
