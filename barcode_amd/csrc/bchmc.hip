@@ -1815,7 +1815,8 @@ int bchmc_upload(bchmc_handle *h, bchmc_field field, const double *host, size_t 
   CHK(DISPATCH(h, upload(h, field, h->dstage)));
   HIPCHK(hipStreamSynchronize(h->stream));
   h->have[field] = true;
-  h->cg_valid = h->prop_g_valid = false;  // the carried gradient belonged to the old inputs
+  // gradient_psi and -log L do not involve the mass (it enters the kinetic term and the drift only)
+  if (field != BCHMC_F_MASS_F && field != BCHMC_F_MASS_R) h->cg_valid = h->prop_g_valid = false;
   return BCHMC_OK;
 }
 

@@ -23,7 +23,7 @@ SHIM_EXPORTS = ("bchmc_shim_Hamiltonian_EoM", "bchmc_shim_delta_Hamiltonian", "b
                 "bchmc_shim_eps_create", "bchmc_shim_eps_destroy", "bchmc_shim_eps_append", "bchmc_shim_eps_records",
                 "bchmc_shim_eps_acceptance_rate", "bchmc_shim_update_eps_fac", "bchmc_shim_update_tables",
                 "bchmc_shim_comm_bootstrap_file", "bchmc_shim_comm_attach", "bchmc_shim_comm_release",
-                "bchmc_shim_inputs_changed")
+                "bchmc_shim_inputs_changed", "bchmc_shim_mass_changed")
 
 _dp = C.POINTER(C.c_double)
 
@@ -60,6 +60,7 @@ class HamilView(C.Structure):
         ("device", C.c_int), ("engine", C.c_void_p),
         ("eps", C.c_void_p), ("comm", C.c_void_p), ("comm_rank", C.c_int),
         ("inputs_generation", C.c_ulong), ("uploaded_generation", C.c_ulong), ("deterministic", C.c_int),
+        ("mass_generation", C.c_ulong), ("mass_uploaded_generation", C.c_ulong),
     ]
 
 
@@ -122,6 +123,8 @@ def load():
     lib.bchmc_shim_comm_release.restype = None
     lib.bchmc_shim_inputs_changed.argtypes = [hv]
     lib.bchmc_shim_inputs_changed.restype = None
+    lib.bchmc_shim_mass_changed.argtypes = [hv]
+    lib.bchmc_shim_mass_changed.restype = None
     lib.bchmc_shim_sizeof_attempt_log.restype = sz
     lib.bchmc_shim_release.argtypes = [hv]
     lib.bchmc_shim_release.restype = None
@@ -296,6 +299,10 @@ class ShimHamil:
 
     def inputs_changed(self):
         self.lib.bchmc_shim_inputs_changed(C.byref(self.hd))
+
+    def mass_changed(self):
+        """Only mass_f / mass_r were rewritten (HMC.cc:400-423): the resident chain keeps its carried gradient."""
+        self.lib.bchmc_shim_mass_changed(C.byref(self.hd))
 
     def out(self, name):
         """hd->gradpsi / deltaX / posx / posy / posz as the C++ layer left them."""

@@ -40,6 +40,16 @@ bchmc_handle *engine_for(HamilView *hd) {
     if (hd->uploaded_generation != hd->inputs_generation) {  // inputs_changed() since the last upload
       upload_inputs(hd, h);
       hd->uploaded_generation = hd->inputs_generation;
+      hd->mass_uploaded_generation = hd->mass_generation;
+    } else if (hd->mass_uploaded_generation != hd->mass_generation) {  // mass_changed(): the two mass arrays only
+      const HamilNumericalView *n = hd->numerical;
+      struct { bchmc_field f; const real_prec *p; } arr[] = {{BCHMC_F_MASS_F, hd->mass_f}, {BCHMC_F_MASS_R, hd->mass_r}};
+      for (auto &a : arr)
+        if (a.p) {
+          const int rc = bchmc_upload(h, a.f, a.p, n->N);
+          if (rc) fail(h, rc, "bchmc_upload");
+        }
+      hd->mass_uploaded_generation = hd->mass_generation;
     }
     return h;
   }
@@ -78,6 +88,7 @@ bchmc_handle *engine_for(HamilView *hd) {
   hd->engine = h;
   upload_inputs(hd, h);
   hd->uploaded_generation = hd->inputs_generation;
+  hd->mass_uploaded_generation = hd->mass_generation;
   return h;
 }
 
@@ -340,6 +351,10 @@ void inputs_changed(HamilView *hd) {
   if (hd) hd->inputs_generation++;  // the next engine_for() uploads the arrays again (once, not per call)
 }
 
+void mass_changed(HamilView *hd) {
+  if (hd) hd->mass_generation++;
+}
+
 void release(HamilView *hd) {
   if (hd && hd->engine) {
     bchmc_destroy(static_cast<bchmc_handle *>(hd->engine));
@@ -482,6 +497,7 @@ int bchmc_shim_comm_attach(bchmc_shim::HamilView *hd, bchmc_comm *comm, int rank
 }
 void bchmc_shim_comm_release(bchmc_shim::HamilView *hd) { bchmc_shim::comm_release(hd); }
 void bchmc_shim_inputs_changed(bchmc_shim::HamilView *hd) { bchmc_shim::inputs_changed(hd); }
+void bchmc_shim_mass_changed(bchmc_shim::HamilView *hd) { bchmc_shim::mass_changed(hd); }
 size_t bchmc_shim_sizeof_attempt_log(void) { return sizeof(bchmc_shim::AttemptLog); }
 void bchmc_shim_release(bchmc_shim::HamilView *hd) { bchmc_shim::release(hd); }
 size_t bchmc_shim_sizeof_view(void) { return sizeof(bchmc_shim::HamilView); }

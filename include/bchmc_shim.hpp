@@ -73,6 +73,9 @@ struct HamilView {
   // re-reads the mass (HMC.cc:400-423); engine_for() uploads only when it differs from what the engine holds
   unsigned long inputs_generation = 0, uploaded_generation = 0;
   int deterministic = 0;  // bchmc_config.deterministic: bitwise repeatable mass assignment (fixed point)
+  // the same for mass_f / mass_r alone (mass_changed()): what HamiltonianMC rewrites every sample.  Unlike the other
+  // inputs the mass does not enter gradient_psi or -log L, so the resident chain keeps its carried gradient.
+  unsigned long mass_generation = 0, mass_uploaded_generation = 0;
 };
 
 // Stand-in for gsl_rng_uniform(seed): called exactly where the reference calls it, in its order.
@@ -165,6 +168,8 @@ void comm_release(HamilView *hd);
 
 // hd's input arrays changed (HamiltonianMC recomputes the mass every sample, HMC.cc:400-423): upload them again
 void inputs_changed(HamilView *hd);
+// only hd->mass_f / hd->mass_r changed (HMC.cc:400-423): upload those two again
+void mass_changed(HamilView *hd);
 void release(HamilView *hd);
 
 }  // namespace bchmc_shim
@@ -205,6 +210,7 @@ int bchmc_shim_comm_bootstrap_file(bchmc_shim::HamilView *hd, const char *path, 
 int bchmc_shim_comm_attach(bchmc_shim::HamilView *hd, bchmc_comm *comm, int rank); /* tests: a custom-transport communicator */
 void bchmc_shim_comm_release(bchmc_shim::HamilView *hd);
 void bchmc_shim_inputs_changed(bchmc_shim::HamilView *hd);
+void bchmc_shim_mass_changed(bchmc_shim::HamilView *hd);
 size_t bchmc_shim_sizeof_attempt_log(void);
 void bchmc_shim_release(bchmc_shim::HamilView *hd);
 size_t bchmc_shim_sizeof_view(void);

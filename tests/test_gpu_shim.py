@@ -96,3 +96,37 @@ def test_cpp_hamiltonian_mc_loop_matches_the_python_mirror():
             assert abs(a["dH"] - b["dH"]) <= 1e-8 * scale
         assert lc[-1]["accepted"] or len(lc) == 30
     assert rel_l2(x_cpp, x_py) < 1e-11
+
+
+def test_mass_changed_keeps_the_carried_gradient_and_uses_the_new_mass(monkeypatch):
+    """HamiltonianMC rewrites mass_f every sample (HMC.cc:400-423): mass_changed() re-uploads the two mass arrays only,
+    and the chain's carried gradient_psi / -log L (which do not involve the mass) survive it.  The samples must be the
+    ones a chain that re-evaluates everything produces."""
+    from barcode_amd.shim import ShimHamil
+    c = Case(Nx=16, likelihood=1, rsd_model=1)
+
+    def run():
+        arrays = c.arrays()
+        arrays["mass_f"] = arrays["mass_f"].copy()
+        rng = np.random.default_rng(7)
+        u = lambda: float(rng.random())  # noqa: E731
+        hd = ShimHamil(c.p, N_eps_fac=3.0, eps_fac=4 * c.eps, **arrays)
+        hd.chain_set_state(c.q0)
+        logs = []
+        for s in range(3):
+            logs += hd.HamiltonianMC(u, seed=11, itmax=20)
+            arrays["mass_f"] *= 1.5          # the caller-owned array HAMIL_DATA::mass_f points at
+            hd.mass_changed()
+        x = hd.chain_get_state()
+        hd.close()
+        return logs, x
+
+    logs_a, x_a = run()
+    monkeypatch.setenv("BCHMC_NO_FORCE_CARRY", "1")
+    logs_b, x_b = run()
+    assert len(logs_a) == len(logs_b) >= 3
+    for a, b in zip(logs_a, logs_b):
+        assert a["accepted"] == b["accepted"] and a["Neps"] == b["Neps"]
+        scale = max(abs(b[k]) for k in ("H_kin_i", "psi_prior_i", "psi_likeli_i", "H_kin_f", "psi_prior_f", "psi_likeli_f"))
+        assert abs(a["dH"] - b["dH"]) <= 1e-9 * scale
+    assert rel_l2(x_a, x_b) < 1e-11
