@@ -961,6 +961,14 @@ struct Pipe {
     return BCHMC_OK;
   }
 
+  // planes mode: the SPH-adjoint path (three V components) with a supported grid
+  static bool planes_on(const bchmc_handle *h) {
+    return h->planes_ok && h->c.calc_h == 2 && h->c.mk == 3 && !env_on("BCHMC_NO_PLANES");
+  }
+  // ... also for the force evaluation before the first step and for the first and the last step (BX_FIRST / BX_LAST
+  // variants of k_step_boundary_x); BCHMC_NO_PLANES_ENDS=1 keeps those on the 3-D plans
+  static bool planes_everywhere(const bchmc_handle *h) { return planes_on(h) && !env_on("BCHMC_NO_PLANES_ENDS"); }
+
   // Hamiltonian_EoM (HMC.cc:275-365) on the k-space state already in (qk, pk).
   // g0_in: the gradient at the start state if the caller has it (the evaluation of HMC.cc:279 is skipped);
   // g0_out: where to keep a copy of it when it is evaluated here.
@@ -982,22 +990,42 @@ struct Pipe {
     int like_mode = 2;
     double b = 0.;
     // 0) gradient at t = 0 (HMC.cc:279-280)
+    // the k-space kernels produce the Zel'dovich Psi^ as a by-product; the ALPT model needs its own pipeline
+    const bool fused_za = (h->c.likelihood != 3) && !uses_alpt(h, h->c.rsd_model);
+    const double c_za = -h->c.D1 * h->c.deltaQ_factor / (double)h->g.N;
+    const bool fused = fused_za && !h->mass_rs && !env_on("BCHMC_NO_FUSE");
     if (!g0_in) {
-      CHK(force_sources(h, false, &like_mode, &b));
-      if (tap && tap->like_i) CHK(tap_loglike(h, tap->like_i));
-      CHK(launch_assemble<false>(h, a, b, like_mode, 0., nullptr));
+      if (fused && planes_everywhere(h)) {
+        // the same evaluation on the 2-D plans: Psi^ with its inverse x passes, V^ assembled after forward x passes
+        StepCtl nc{h->stop, h->steps_done, nullptr, 0., 0};
+        {
+          ProfScope ps(h, BCHMC_K_KSPACE_DRIFT_ZA);
+          CHK(launch_boundary_x<BX_FIRST>(h, C(h->qk), nullptr, nullptr, nullptr, nullptr, 0., 0., 0., 0., c_za, nullptr,
+                                          nc, nullptr, nullptr));
+        }
+        h->planes_c2r = h->planes_r2c = true;
+        const int rc = force_sources(h, true, &like_mode, &b);
+        h->planes_c2r = h->planes_r2c = false;
+        CHK(rc);
+        if (like_mode != 0) return h->fail(BCHMC_ERR_STATE, "planes mode without the three V components");
+        if (tap && tap->like_i) CHK(tap_loglike(h, tap->like_i));
+        h->prop_g_valid = false;
+        ProfScope ps(h, BCHMC_K_KSPACE_FORCE_KICK);
+        CHK(launch_boundary_x<BX_LAST>(h, C(h->qk), nullptr, nullptr, nullptr, nullptr, a, b, 0., 0., 0., nullptr, nc,
+                                       nullptr, C(h->gk)));
+      } else {
+        CHK(force_sources(h, false, &like_mode, &b));
+        if (tap && tap->like_i) CHK(tap_loglike(h, tap->like_i));
+        CHK(launch_assemble<false>(h, a, b, like_mode, 0., nullptr));
+      }
       if (g0_out)
         HIPCHK(hipMemcpyAsync(g0_out, h->gk, 2 * (size_t)h->g.Nhp * sizeof(T), hipMemcpyDeviceToDevice, h->stream));
     }
     const void *g_first = g0_in ? g0_in : h->gk;
 
-    // the k-space kernels produce the Zel'dovich Psi^ as a by-product; the ALPT model needs its own pipeline
-    const bool fused_za = (h->c.likelihood != 3) && !uses_alpt(h, h->c.rsd_model);
     const double *wM = h->mass_fs ? h->wM : nullptr;
-    const double c_za = -h->c.D1 * h->c.deltaQ_factor / (double)h->g.N;
     const double guard_limit = 1e50 * (double)h->g.N;
-    if (fused_za && !h->mass_rs && !env_on("BCHMC_NO_FUSE"))
-      return trajectory_fused(h, eps, neps, tap, a, wM, c_za, g_first);
+    if (fused) return trajectory_fused(h, eps, neps, tap, a, wM, c_za, g_first);
     for (uint64_t s = 0; s < neps; s++) {
       StepCtl ctl{h->stop, h->steps_done, s > 0 ? h->guard + (s - 1) : nullptr, guard_limit, s};
       if (!h->mass_rs) {
@@ -1029,8 +1057,10 @@ struct Pipe {
   }
 
   // k_step_boundary_x for this grid: n == PER * NT / KB with KB = 8 (fp64, NT = 256) or 16 (fp32, NT = 512)
+  template <int MODE = BX_INTERIOR>
   static int launch_boundary_x(bchmc_handle *h, const CT *qi, const CT *pi, CT *qo, CT *po, const double *wM, double a,
-                               double b, double half_eps, double eps, double c_za, double *guard_slot, StepCtl ctl) {
+                               double b, double half_eps, double eps, double c_za, double *guard_slot, StepCtl ctl,
+                               const CT *g_in = nullptr, CT *g_out = nullptr) {
     constexpr int KB = 128 / (int)sizeof(CT);
     constexpr int NT_BIG = sizeof(T) == 8 ? 256 : 512, NT_SMALL = NT_BIG / 4;  // small: n = 32, 64 (tests)
     const int n = h->g.n, grid = n * (h->g.nhp / KB);
@@ -1038,12 +1068,12 @@ struct Pipe {
     const CT *tw = reinterpret_cast<const CT *>(h->xtw);
 #define BCHMC_LAUNCH_X(NT, PER)                                                                                    \
   do {                                                                                                             \
-    auto kern = k_step_boundary_x<T, NT, PER>;                                                                     \
+    auto kern = k_step_boundary_x<T, NT, PER, MODE>;                                                               \
     if (lds > 48 * 1024)                                                                                           \
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                  (int)lds));                                                                       \
     kern<<<grid, NT, lds, h->stream>>>(h->g, h->log2n, tw, C(h->Ck), qi, pi, qo, po, h->wS, wM, a, b, half_eps,  \
-                                       eps, c_za, guard_slot, ctl);                                                \
+                                       eps, c_za, guard_slot, ctl, g_in, g_out);                                   \
   } while (0)
     switch (n) {
       case 32: BCHMC_LAUNCH_X(NT_SMALL, 4); break;
@@ -1071,19 +1101,23 @@ struct Pipe {
     int like_mode = 2;
     double b = 0.;
     int cur = 0;  // boundary j reads pair j % 2
+    const bool planes = planes_on(h), ends = planes_everywhere(h);
     {
       StepCtl ctl{h->stop, h->steps_done, nullptr, guard_limit, 0};
       ProfScope ps(h, BCHMC_K_KSPACE_DRIFT_ZA);
-      k_kick_drift_za<T, true><<<nblk_stride(h->g.Nhp), 256, 0, h->stream>>>(h->g, C(q0), C(p0), C(g_first), wM, nullptr,
-                                                                           C(h->Ck), 0.5 * eps, eps, c_za, ctl);
+      if (ends) {
+        CHK(launch_boundary_x<BX_FIRST>(h, C(q0), C(p0), C(q0), C(p0), wM, 0., 0., 0.5 * eps, eps, c_za, nullptr, ctl,
+                                        C(g_first), nullptr));
+      } else {
+        k_kick_drift_za<T, true><<<nblk_stride(h->g.Nhp), 256, 0, h->stream>>>(h->g, C(q0), C(p0), C(g_first), wM,
+                                                                             nullptr, C(h->Ck), 0.5 * eps, eps, c_za, ctl);
+      }
       HIPCHK(hipGetLastError());
     }
-    // planes mode: the SPH-adjoint path (three V components) with a supported grid
-    const bool planes = h->planes_ok && h->c.calc_h == 2 && h->c.mk == 3 && !env_on("BCHMC_NO_PLANES");
     for (uint64_t s = 0; s < neps; s++) {
       const bool last = (s + 1 == neps);
-      h->planes_c2r = planes && s > 0;   // Psi^ left by k_step_boundary_x still needs only the (y, z) passes
-      h->planes_r2c = planes && !last;   // ... and V^ for it gets only those
+      h->planes_c2r = planes && (s > 0 || ends);  // Psi^ left by k_step_boundary_x still needs only the (y, z) passes
+      h->planes_r2c = planes && (!last || ends);  // ... and V^ for it gets only those
       const int rc = force_sources(h, true, &like_mode, &b);
       const bool xmode = h->planes_r2c && like_mode == 0;
       h->planes_c2r = h->planes_r2c = false;
@@ -1092,7 +1126,10 @@ struct Pipe {
       StepCtl ctl{h->stop, h->steps_done, s > 0 ? h->guard + (s - 1) : nullptr, guard_limit, s};
       void *qi = cur ? q1 : q0, *pi = cur ? p1 : p0, *qo = cur ? q0 : q1, *po = cur ? p0 : p1;
       ProfScope ps(h, BCHMC_K_KSPACE_FORCE_KICK);
-      if (last) {
+      if (last && xmode) {
+        CHK(launch_boundary_x<BX_LAST>(h, C(qi), C(pi), nullptr, C(pi), wM, a, b, 0.5 * eps, eps, c_za, h->guard + s, ctl,
+                                       nullptr, C(h->gk)));
+      } else if (last) {
         k_step_boundary<T, true><<<nblk_stride(h->g.Nhp), 256, 0, h->stream>>>(
             h->g, C(h->Ck), C(qi), C(pi), C(qi), C(pi), C(h->gk), h->wS, wM, a, b, like_mode, 0.5 * eps, eps, c_za,
             h->guard + s, ctl);

@@ -95,23 +95,36 @@ __device__ __forceinline__ void xfft_inplace(C2<T> *__restrict__ s, const C2<T> 
   }
 }
 
-template <typename T, int NT, int PER>
+// MODE selects which half of the boundary exists, so that the first and the last step of a trajectory (and the force
+// evaluation before the first step) run on the 2-D plans as well:
+//   BX_INTERIOR  forward x passes of V^, g^, both half kicks, drift, Psi^' with its inverse x passes (described above);
+//   BX_FIRST     no V^ yet: g^ is read from g_in (k_kick_drift_za: one half kick, drift), Psi^' with inverse x passes;
+//                g_in == nullptr: Psi^ of q_in only, nothing else read or written (launch_za), no trajectory control;
+//   BX_LAST      forward x passes of V^, g^ stored to g_out, p_out = p - (eps/2) g^ (k_step_boundary<LAST>);
+//                p_out == nullptr: g^ only (k_assemble<false>), no trajectory control.
+enum { BX_INTERIOR = 0, BX_FIRST = 1, BX_LAST = 2 };
+
+template <typename T, int NT, int PER, int MODE = BX_INTERIOR>
 __global__ void __launch_bounds__(NT, BCHMC_BX_WAVES)
 k_step_boundary_x(Geo g, int log2n, const C2<T> *__restrict__ twiddle, C2<T> *Ck, const C2<T> *q_in, const C2<T> *p_in,
                   C2<T> *q_out, C2<T> *p_out, const double *__restrict__ wS, const double *__restrict__ wM, double a,
-                  double b, double half_eps, double eps, double c_za, double *guard_slot, StepCtl ctl) {
+                  double b, double half_eps, double eps, double c_za, double *guard_slot, StepCtl ctl,
+                  const C2<T> *g_in = nullptr, C2<T> *g_out = nullptr) {
   constexpr int KB = 128 / (int)sizeof(C2<T>);
   constexpr int kMaxPer = PER;  // elements of one component per thread: n == PER * NT / KB (checked by the host)
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw_x[];
   __shared__ double red[NT / 64];
-  if (*ctl.stop) return;
-  if (ctl.guard_prev && fabs(*ctl.guard_prev) > ctl.guard_limit) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-      *ctl.steps_done = ctl.step_index;
-      __threadfence();
-      *ctl.stop = 1;
+  const bool controlled = MODE == BX_INTERIOR || (MODE == BX_FIRST && g_in) || (MODE == BX_LAST && p_out);
+  if (controlled) {
+    if (*ctl.stop) return;
+    if (ctl.guard_prev && fabs(*ctl.guard_prev) > ctl.guard_limit) {
+      if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *ctl.steps_done = ctl.step_index;
+        __threadfence();
+        *ctl.stop = 1;
+      }
+      return;
     }
-    return;
   }
   const int n = g.n;
   C2<T> *s = reinterpret_cast<C2<T> *>(s_raw_x);  // n * KB
@@ -129,7 +142,7 @@ k_step_boundary_x(Geo g, int log2n, const C2<T> *__restrict__ twiddle, C2<T> *Ck
   double2 hk[kMaxPer];
   // ---- forward x passes.  ky and kz are constants of a column, so V^_y and V^_z go through ONE transform as
   // ky V_y + kz V_z:  h^ = (1/k^2) [ kx (Im V^_x, -Re V^_x) + (Im W^, -Re W^) ],  W = ky V_y + kz V_z ----
-  for (int pass = 0; pass < 2; pass++) {
+  for (int pass = 0; pass < (MODE == BX_FIRST ? 0 : 2); pass++) {
     __syncthreads();
     for (int m = 0; m < per; m++) {
       const int i = irow + rows * m;
@@ -172,33 +185,63 @@ k_step_boundary_x(Geo g, int log2n, const C2<T> *__restrict__ twiddle, C2<T> *Ck
     const double ksq = kx * kx + ky * ky + kz * kz;
     const bool nyq = (i == g.n / 2) || (j == g.n / 2) || (k == g.n / 2);
     double2 q = ld2<T>(q_in, idx);
-    double2 gg = make_double2(0., 0.);
-    if (ksq > 0 && !nyq) {
-      const double f = b * (1 / ksq);
-      gg = make_double2(f * hk[m].x, f * hk[m].y);
+    if (MODE == BX_FIRST) {
+      if (g_in) {  // k_kick_drift_za<DRIFT>: the drift uses the kicked momentum before it is rounded to T
+        double2 p = ld2<T>(p_in, idx);
+        const double2 g0 = ld2<T>(g_in, idx);
+        p.x -= half_eps * g0.x;
+        p.y -= half_eps * g0.y;
+        st2<T>(p_out, idx, p.x, p.y);
+        if (wM) {
+          const double w = wM[idx];
+          q.x += eps * (w * p.x);
+          q.y += eps * (w * p.y);
+        }
+        st2<T>(q_out, idx, q.x, q.y);
+      }
+    } else {
+      double2 gg = make_double2(0., 0.);
+      if (ksq > 0 && !nyq) {
+        const double f = b * (1 / ksq);
+        gg = make_double2(f * hk[m].x, f * hk[m].y);
+      }
+      if (a != 0.) {
+        const double w = a * wS[idx];
+        gg.x += w * q.x;
+        gg.y += w * q.y;
+      }
+      C2<T> gs;
+      gs.x = (T)gg.x;
+      gs.y = (T)gg.y;
+      if (MODE == BX_LAST) {
+        g_out[idx] = gs;
+        if (p_out) {
+          const double2 p = ld2<T>(p_in, idx);
+          C2<T> pe;
+          pe.x = (T)(p.x - half_eps * gg.x);
+          pe.y = (T)(p.y - half_eps * gg.y);
+          const double hw = (k == 0 || ((g.n & 1) == 0 && k == g.n / 2)) ? 1. : 2.;
+          if (k < g.nh) gsum += hw * (double)pe.x;
+          p_out[idx] = pe;
+        }
+        continue;
+      }
+      double2 p = ld2<T>(p_in, idx);
+      C2<T> pe;
+      pe.x = (T)(p.x - half_eps * gg.x);
+      pe.y = (T)(p.y - half_eps * gg.y);
+      const double hw = (k == 0 || ((g.n & 1) == 0 && k == g.n / 2)) ? 1. : 2.;
+      if (k < g.nh) gsum += hw * (double)pe.x;
+      p.x = (double)pe.x - half_eps * (double)gs.x;
+      p.y = (double)pe.y - half_eps * (double)gs.y;
+      st2<T>(p_out, idx, p.x, p.y);
+      if (wM) {
+        const double w = wM[idx];
+        q.x += eps * (w * p.x);
+        q.y += eps * (w * p.y);
+      }
+      st2<T>(q_out, idx, q.x, q.y);
     }
-    if (a != 0.) {
-      const double w = a * wS[idx];
-      gg.x += w * q.x;
-      gg.y += w * q.y;
-    }
-    double2 p = ld2<T>(p_in, idx);
-    C2<T> pe, gs;
-    pe.x = (T)(p.x - half_eps * gg.x);
-    pe.y = (T)(p.y - half_eps * gg.y);
-    gs.x = (T)gg.x;
-    gs.y = (T)gg.y;
-    const double hw = (k == 0 || ((g.n & 1) == 0 && k == g.n / 2)) ? 1. : 2.;
-    if (k < g.nh) gsum += hw * (double)pe.x;
-    p.x = (double)pe.x - half_eps * (double)gs.x;
-    p.y = (double)pe.y - half_eps * (double)gs.y;
-    st2<T>(p_out, idx, p.x, p.y);
-    if (wM) {
-      const double w = wM[idx];
-      q.x += eps * (w * p.x);
-      q.y += eps * (w * p.y);
-    }
-    st2<T>(q_out, idx, q.x, q.y);
     C2<T> o;
     o.x = T(0);
     o.y = T(0);
@@ -208,6 +251,13 @@ k_step_boundary_x(Geo g, int log2n, const C2<T> *__restrict__ twiddle, C2<T> *Ck
       o.y = (T)(f * -(c_za * q.x));
     }
     s[(int)(__brev((unsigned)i) >> shift) * KB + c] = o;
+  }
+  if (MODE == BX_LAST) {
+    if (p_out) {
+      gsum = block_sum(gsum, red);
+      if (threadIdx.x == 0) atomic_add_r(guard_slot, gsum);
+    }
+    return;
   }
   __syncthreads();
   xfft_inplace<T>(s, tw, n, log2n, KB, true);
@@ -226,7 +276,7 @@ k_step_boundary_x(Geo g, int log2n, const C2<T> *__restrict__ twiddle, C2<T> *Ck
     o.y = T(0);
     if (ksq > 1.e-14 && !nyq) {
       // q' as stored (each thread re-reads its own stores; for T = float this is the rounded value)
-      const double2 qn = ld2<T>(q_out, col + plane * i);
+      const double2 qn = ld2<T>((MODE == BX_FIRST && !g_in) ? q_in : q_out, col + plane * i);
       const double f = 1. / ksq;
       o.x = (T)(f * (c_za * qn.y));
       o.y = (T)(f * -(c_za * qn.x));
@@ -246,8 +296,10 @@ k_step_boundary_x(Geo g, int log2n, const C2<T> *__restrict__ twiddle, C2<T> *Ck
     Ck[col + plane * i + g.Nhp] = oy;
     Ck[col + plane * i + 2 * g.Nhp] = oz;
   }
-  gsum = block_sum(gsum, red);
-  if (threadIdx.x == 0) atomic_add_r(guard_slot, gsum);
+  if (MODE == BX_INTERIOR) {
+    gsum = block_sum(gsum, red);
+    if (threadIdx.x == 0) atomic_add_r(guard_slot, gsum);
+  }
 }
 
 }  // namespace bchmc
