@@ -217,13 +217,13 @@ k_partial_like(Geo g, LikePar lp, const T *__restrict__ rho, const double *__res
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < g.N;
        i += (long long)gridDim.x * blockDim.x) {
     const double dX = (double)rho[i] / nmean - 1.;
-    const double w = window[i];
+    const double w = stream_load<BCHMC_NT_LIKE != 0>(window + i);
     double out = 0.;
     if (lp.likelihood == 1) {
       const double Lambda = w * lp.rho_c * pow_bias(1. + lp.biasP * dX, lp);
       if ((w > 0.) && (Lambda > 0.0)) {
-        const double s = noise[i];
-        out = ((double)nobs[i] - Lambda) / (s * s);
+        const double s = stream_load<BCHMC_NT_LIKE != 0>(noise + i);
+        out = ((double)stream_load<BCHMC_NT_LIKE != 0>(nobs + i) - Lambda) / (s * s);
       }
     } else if (lp.likelihood == 0) {
       const double dens = 1. + lp.biasP * dX;

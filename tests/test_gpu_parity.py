@@ -361,15 +361,22 @@ def test_planes_mode_other_likelihoods(monkeypatch, kw):
 @pytest.mark.parametrize("nx,precision", [(32, 0), (32, 1), (64, 0)], ids=["n32_fp64", "n32_fp32", "n64_fp64"])
 def test_planes_mode_step_boundary(monkeypatch, nx, precision):
     """Interior step boundaries in "planes" mode (2-D rocFFT transforms of the (y, z) planes, the x passes fused into
-    k_step_boundary_x) against the oracle and against the 3-D-transform path (BCHMC_NO_PLANES=1)."""
+    k_step_boundary_x; its BX_FIRST / BX_LAST variants at the ends of the trajectory and for the force evaluation before
+    the first step) against the oracle, against planes mode for interior steps only (BCHMC_NO_PLANES_ENDS=1) and
+    against the 3-D-transform path (BCHMC_NO_PLANES=1); a one-step trajectory is first and last step at once."""
     monkeypatch.setenv("BCHMC_FFT_PAD", "1")  # whole 128-byte k-groups per row (default only for n >= 128)
     c = Case(Nx=nx, likelihood=1, rsd_model=1)
     neps = 4
     q1o, p1o, _ = c.oracle.Hamiltonian_EoM(c.q0, c.p0, c.eps, neps)
+    q1o_1, p1o_1, _ = c.oracle.Hamiltonian_EoM(c.q0, c.p0, c.eps, 1)
     out = []
-    for no_planes in ("0", "1"):
+    tol = TOL_TRAJ_10 if precision == 0 else TOL_F32_TRAJ
+    for no_planes, no_ends in (("0", "0"), ("0", "1"), ("1", "0")):
         monkeypatch.setenv("BCHMC_NO_PLANES", no_planes)
+        monkeypatch.setenv("BCHMC_NO_PLANES_ENDS", no_ends)
         e = c.engine(precision=precision)
+        qs, ps_, done = e.leapfrog(c.q0, c.p0, c.eps, 1)
+        assert done == 1 and rel_l2(qs, q1o_1) < tol and rel_l2(ps_, p1o_1) < tol
         q1, p1, done = e.leapfrog(c.q0, c.p0, c.eps, neps)
         assert done == neps
         qb = pb = np.zeros(1)
@@ -380,13 +387,13 @@ def test_planes_mode_step_boundary(monkeypatch, nx, precision):
             assert doneb == 1
         out.append((q1, p1, qb, pb))
         e.close()
-    tol = TOL_TRAJ_10 if precision == 0 else TOL_F32_TRAJ
     for q1, p1, _, _ in out:
         assert rel_l2(q1, q1o) < tol and rel_l2(p1, p1o) < tol
     noise = 1e-13 if precision == 0 else 1e-5
-    assert rel_l2(out[0][0], out[1][0]) < noise and rel_l2(out[0][1], out[1][1]) < noise
-    if precision == 0:
-        assert rel_l2(out[0][2], out[1][2]) < noise and rel_l2(out[0][3], out[1][3]) < noise
+    for other in out[1:]:
+        assert rel_l2(out[0][0], other[0]) < noise and rel_l2(out[0][1], other[1]) < noise
+        if precision == 0:
+            assert rel_l2(out[0][2], other[2]) < noise and rel_l2(out[0][3], other[3]) < noise
 
 
 def test_device_resident_entry_points():
