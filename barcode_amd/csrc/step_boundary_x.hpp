@@ -221,6 +221,7 @@ k_step_boundary_x(Geo g, int log2n, const C2<T> *__restrict__ twiddle, C2<T> *Ck
   // Psi^_j = k_j B with B = (1/k^2)(Im phi^, -Re phi^), phi^ = c_za q^': kx B is transformed on its own, B once for
   // both the y and the z component (ky, kz are constants of the column again).
   double gsum = 0.;
+  C2<T> qkeep[kMaxPer];  // q' as stored (rounded to T), for the second inverse pass: registers are free up to 128 here
   __syncthreads();
 #pragma unroll
   for (int m = 0; m < kMaxPer; m++) {
@@ -302,6 +303,8 @@ k_step_boundary_x(Geo g, int log2n, const C2<T> *__restrict__ twiddle, C2<T> *Ck
         bx_store(q_out + idx, t);
       }
     }
+    qkeep[m].x = (T)q.x;
+    qkeep[m].y = (T)q.y;
     C2<T> o;
     o.x = T(0);
     o.y = T(0);
@@ -326,7 +329,8 @@ k_step_boundary_x(Geo g, int log2n, const C2<T> *__restrict__ twiddle, C2<T> *Ck
     bx_store(Ck + col + plane * i, s[i * KB + c]);
   }
   __syncthreads();
-  for (int m = 0; m < per; m++) {
+#pragma unroll
+  for (int m = 0; m < kMaxPer; m++) {
     const int i = irow + rows * m;
     const double kx = kval(i, g.n, g.kfac);
     const double ksq = kx * kx + ky * ky + kz * kz;
@@ -335,8 +339,7 @@ k_step_boundary_x(Geo g, int log2n, const C2<T> *__restrict__ twiddle, C2<T> *Ck
     o.x = T(0);
     o.y = T(0);
     if (ksq > 1.e-14 && !nyq) {
-      // q' as stored (each thread re-reads its own stores; for T = float this is the rounded value)
-      const double2 qn = ld2<T>((MODE == BX_FIRST && !g_in) ? q_in : q_out, col + plane * i);
+      const double2 qn = make_double2((double)qkeep[m].x, (double)qkeep[m].y);
       const double f = 1. / ksq;
       o.x = (T)(f * (c_za * qn.y));
       o.y = (T)(f * -(c_za * qn.x));
