@@ -56,14 +56,20 @@ __device__ __forceinline__ float r_max(float a, float b) { return fmaxf(a, b); }
 __device__ __forceinline__ double r_fma(double a, double b, double c) { return fma(a, b, c); }
 __device__ __forceinline__ float r_fma(float a, float b, float c) { return fmaf(a, b, c); }
 
-// pacman_coordinate, pacman.cpp:20-28
+// pacman_coordinate, pacman.cpp:20-28: if (x < 0) { x = fmod(x, L); x += L; }  if (x >= L) x = fmod(x, L);
+// Same results without the fmod expansion on the paths that occur: for -L < x < 0 fmod(x, L) is x itself, and for
+// L <= x < 2L it is x - L, which the subtraction gives exactly (Sterbenz); farther out (a blown-up trajectory) the
+// library function runs.  The order of the two tests is the reference's (x + L may round to L and is then folded to 0).
 template <typename T>
 __device__ __forceinline__ T pacman(T x, T L) {
   if (x < T(0)) {
-    x = r_fmod(x, L);
+    if (__builtin_expect(!(x > -L), 0)) x = r_fmod(x, L);
     x += L;
   }
-  if (x >= L) x = r_fmod(x, L);
+  if (x >= L) {
+    if (__builtin_expect(!(x < L + L), 0)) x = r_fmod(x, L);
+    else x = x - L;
+  }
   return x;
 }
 

@@ -121,8 +121,10 @@ __device__ __forceinline__ int home_cell_i(const HomeCell<T> &hc, T x) {
   return (int)f;
 }
 __device__ __forceinline__ int wrap_cell(int c, int n) { return c >= n ? c - n : c; }
+// tile sides are powers of two (4, 8 or 16: bchmc_create): shifts, not three integer divisions per particle
 __device__ __forceinline__ int tile_of_wrapped(const TilePar &tp, int cx, int cy, int cz) {
-  return (cz / tp.tz) + tp.ntz * ((cy / tp.ty) + tp.nty * (cx / tp.tx));
+  const int sx = __builtin_ctz(tp.tx), sy = __builtin_ctz(tp.ty), sz = __builtin_ctz(tp.tz);
+  return (cz >> sz) + tp.ntz * ((cy >> sy) + tp.nty * (cx >> sx));
 }
 
 // Workgroup -> particles.  When 16 divides n a workgroup takes a 4 x 4 x 16 brick of the Lagrangian lattice

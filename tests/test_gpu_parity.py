@@ -68,6 +68,27 @@ def test_forward_model_intermediates(case):
     assert rel_l2(c.e.fetch("deltaX"), dX) < TOL_FIELD
 
 
+def test_positions_wrap_far_outside_the_box():
+    """pacman_coordinate (pacman.cpp:20-28) on displacements of many box lengths: the engine folds -L < x < 0 and
+    L <= x < 2L with one exact add / subtract and leaves the rest to fmod; every branch must give the oracle's position
+    (a wrong fold is off by a box length)."""
+    c = Case(Nx=16, likelihood=1, rsd_model=1)
+    e = c.engine()
+    for scale in (1.0, 40.0, 2000.0):   # displacements << L, ~ L, >> L
+        big = c.truth * scale
+        _, px, py, pz = c.oracle.Lag2Eul(big, rsd=1)
+        e.forward(big, 1)
+        L = c.p.L
+        for name, ref in zip(("posx", "posy", "posz"), (px, py, pz)):
+            got = e.fetch(name)
+            assert got.min() >= 0. and got.max() <= L
+            # compare on the circle: a position within round-off of a face may legitimately land on either side
+            diff = np.abs(got - ref.ravel())
+            diff = np.minimum(diff, L - diff)
+            assert diff.max() < 1e-9 * L * max(scale, 1.), (name, scale, diff.max())
+    e.close()
+
+
 def test_gradient_psi_and_its_pieces(case):
     c = case
     g, gp, gl = c.oracle.gradient_psi(c.q0)
