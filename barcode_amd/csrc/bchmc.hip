@@ -657,6 +657,7 @@ struct Pipe {
       CHK(fft_exec(h, h->planes_c2r ? h->c2r2d : h->c2r3, h->Ck, h->psi, BCHMC_K_FFT_C2R));
     }
     h->sorted_valid = false;
+    bool rho_cleared = false;  // by k_bin_direct, on its way through the lattice
     const PosPar pp = make_pos(h, rsd);
     const SphPar sp = make_sph(h);
     if (h->c.mk == 3 && h->tiled) {
@@ -674,7 +675,9 @@ struct Pipe {
       if (h->sort_direct) {
         const int nsuper = (nbricks + kBinPer - 1) / kBinPer;
         k_bin_direct<T><<<nsuper, BCHMC_BIN_THREADS, 0, h->stream>>>(h->g, pp, sp, h->tp, nsuper, R(h->psi), cnt1, ovf,
-                                                       (RecQuad *)h->srec, R(h->V), h->rho_part);
+                                                       (RecQuad *)h->srec, R(h->V), h->rho_part,
+                                                       h->fix ? nullptr : R(h->rho), h->fix ? h->rho_fix : nullptr);
+        rho_cleared = true;
       } else {
         HIPCHK(hipMemsetAsync(ovf, 1, 1, h->stream));  // non-zero flag: two-pass sort only
       }
@@ -692,10 +695,12 @@ struct Pipe {
       // fixed point (deterministic mode): scale = 2^46 / largest single contribution (W(0) = 1/(pi h^3) for the SPH
       // kernel, 1 for NGP / CIC / TSC weights)
       const double fix_scale = h->c.mk == 3 ? 70368744177664. / sp.w_norm : 70368744177664.;
-      if (h->fix)
+      if (rho_cleared) {
+      } else if (h->fix) {
         HIPCHK(hipMemsetAsync(h->rho_fix, 0, h->g.N * sizeof(long long), h->stream));
-      else
+      } else {
         HIPCHK(hipMemsetAsync(h->rho, 0, h->g.N * sizeof(T), h->stream));
+      }
       if (tile_path) {
         // the tile kernels also leave sum(rho) in rho_part (partial sums of what they flush): no pass over rho
         // (k_bin<DIRECT> has cleared the partials; without the one-pass binning a fill does)

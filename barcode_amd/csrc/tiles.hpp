@@ -191,7 +191,8 @@ __device__ __forceinline__ int super_brick(const Geo &g, int sb, int m) {
 template <typename T>
 __global__ void __launch_bounds__(BCHMC_BIN_THREADS)
 k_bin_direct(Geo g, PosPar pp, SphPar sp, TilePar tp, int nsuper, const T *__restrict__ psi, int *__restrict__ cnt,
-             int *__restrict__ ovf, RecQuad *__restrict__ srec, T *__restrict__ V, double *__restrict__ zero_part) {
+             int *__restrict__ ovf, RecQuad *__restrict__ srec, T *__restrict__ V, double *__restrict__ zero_part,
+             T *__restrict__ rho_zero, long long *__restrict__ fix_zero) {
   constexpr int kSlots = 2048;  // > kBinPer * 256 distinct counters can never occur: the probing always terminates
   __shared__ int hkey[kSlots], hcnt[kSlots], hbase[kSlots];
   // the scatter that follows accumulates sum(rho) into these partials: cleared here instead of by a fill launch
@@ -216,6 +217,9 @@ k_bin_direct(Geo g, PosPar pp, SphPar sp, TilePar tp, int nsuper, const T *__res
       slot[m] = local[m] = flag[m] = 0;
       x[m] = y[m] = z[m] = T(0);
       if (p[m] >= g.N) continue;
+      // the bricks visit every lattice index once: clear the density the scatter accumulates into (no fill launch)
+      if (rho_zero) rho_zero[p[m]] = T(0);
+      if (fix_zero) fix_zero[p[m]] = 0;
       particle_pos<T>(pp, i, j, k, psi[p[m]], psi[p[m] + g.N], psi[p[m] + 2 * g.N], x[m], y[m], z[m]);
       if (pos_ok(g, x[m], y[m], z[m])) {
         const int t = tile_of_wrapped(tp, wrap_cell(home_cell_i(hc, x[m]), g.n), wrap_cell(home_cell_i(hc, y[m]), g.n),
