@@ -369,6 +369,11 @@ int check_inputs(bchmc_handle *h) {
 // they would no longer be addressable / allocatable.  Called at the start of every trajectory and forward model; the
 // flag itself travels with the read-backs that synchronise anyway (read_ctl below: steps_done, bchmc_sync), so the
 // common case costs nothing here.
+int grow_sort_slots(bchmc_handle *h);
+
+// The host's view of the device-side trajectory control; synchronises the stream.  Also the point where an overflow
+// of the one-pass binning's record slots is noticed: they are doubled right here, while the host is waiting anyway,
+// not inside the next trajectory (reallocating several GB takes between a few and a few hundred milliseconds).
 int read_ctl(bchmc_handle *h, unsigned long long *steps_done) {
   unsigned long long sd = 0;
   int seen = 0;
@@ -378,7 +383,10 @@ int read_ctl(bchmc_handle *h, unsigned long long *steps_done) {
                           h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   if (steps_done) *steps_done = sd;
-  if (seen) h->ovf_seen = true;
+  if (seen) {
+    h->ovf_seen = true;
+    CHK(grow_sort_slots(h));
+  }
   return BCHMC_OK;
 }
 
@@ -407,6 +415,7 @@ int grow_sort_slots(bchmc_handle *h) {
   (void)hipFree(h->srec);
   h->srec = nrecs;
   h->tp.cap = (int)cap;
+  if (env_on("BCHMC_VERBOSE")) fprintf(stderr, "bchmc: record slots per tile doubled to %d\n", h->tp.cap);
   return BCHMC_OK;
 }
 
@@ -984,7 +993,7 @@ struct Pipe {
     if (neps + 1 > h->guard_cap) {
       if (h->guard) (void)hipFree(h->guard);
       h->guard = nullptr;
-      h->guard_cap = std::max<size_t>(64, 2 * (neps + 1));
+      h->guard_cap = std::max<size_t>(4096, 2 * (neps + 1));  // generous: a reallocation synchronises the device
       CHK(dev_alloc(h, &h->guard, h->guard_cap));
     }
     HIPCHK(hipMemsetAsync(h->guard, 0, (neps + 1) * sizeof(double), h->stream));
@@ -1947,7 +1956,8 @@ int bchmc_energies(bchmc_handle *h, const double *q, const double *p, double out
   const size_t N = (size_t)h->g.N, bytes = N * sizeof(double);
   CHK(h2d(h, h->dstage, q, bytes));
   CHK(h2d(h, h->dstage + N, p, bytes));
-  return DISPATCH(h, energies_core(h, h->dstage, h->dstage + N, out));
+  CHK(DISPATCH(h, energies_core(h, h->dstage, h->dstage + N, out)));
+  return read_ctl(h, nullptr);
 }
 
 int bchmc_kinetic_term(bchmc_handle *h, const double *p, double *out) {
@@ -1961,7 +1971,8 @@ int bchmc_psi(bchmc_handle *h, const double *q, double out[2]) {
   if (!h || !q || !out) return BCHMC_ERR_ARG;
   ENTER(h);
   CHK(h2d(h, h->dstage, q, (size_t)h->g.N * sizeof(double)));
-  return DISPATCH(h, psi_core(h, h->dstage, out));
+  CHK(DISPATCH(h, psi_core(h, h->dstage, out)));
+  return read_ctl(h, nullptr);
 }
 
 int bchmc_delta_hamiltonian(bchmc_handle *h, const double *qi, const double *pi, const double *qf, const double *pf,
@@ -1993,8 +2004,7 @@ int bchmc_forward(bchmc_handle *h, const double *q, int use_rsd) {
   ENTER(h);
   CHK(h2d(h, h->dstage, q, h->g.N * sizeof(double)));
   CHK(DISPATCH(h, forward(h, h->dstage, use_rsd < 0 ? h->c.rsd_model : (use_rsd ? 1 : 0))));
-  HIPCHK(hipStreamSynchronize(h->stream));
-  return BCHMC_OK;
+  return read_ctl(h, nullptr);  // synchronises; enlarges the binning's record slots if this field overflowed them
 }
 
 int bchmc_gradient(bchmc_handle *h, const double *q, double *gout) {
@@ -2005,7 +2015,7 @@ int bchmc_gradient(bchmc_handle *h, const double *q, double *gout) {
   CHK(h2d(h, h->dstage, q, N * sizeof(double)));
   CHK(DISPATCH(h, gradient(h, h->dstage, h->dstage + N)));
   CHK(d2h(h, gout, h->dstage + N, N * sizeof(double)));
-  return BCHMC_OK;
+  return read_ctl(h, nullptr);
 }
 
 int bchmc_fetch(bchmc_handle *h, bchmc_field field, double *host, size_t n) {
