@@ -145,6 +145,10 @@ int bchmc_leapfrog_device(bchmc_handle *h, const double *d_q0, const double *d_p
                           double eps, uint64_t neps);
 int bchmc_steps_done(bchmc_handle *h, uint64_t *steps_done); /* synchronises */
 int bchmc_energies_device(bchmc_handle *h, const double *d_q, const double *d_p, double out[3]); /* synchronises */
+/* Waits for the handle's stream.  Also the point where the engine adapts its working storage to the field it has just
+ * seen: if a force evaluation overflowed the binning's per-tile record slots (that evaluation itself was still exact,
+ * through the two-pass sort), they are doubled here, so a trajectory never pays for a reallocation.  bchmc_steps_done,
+ * bchmc_forward and the host-array energy / gradient calls do the same. */
 int bchmc_sync(bchmc_handle *h);
 void *bchmc_stream(bchmc_handle *h); /* hipStream_t the engine launches on */
 
