@@ -1793,6 +1793,9 @@ int bchmc_create(const bchmc_config *cfg, bchmc_handle **out) {
             const int zw = (std::abs(c.x) <= 2 && std::abs(c.y) <= 2) ? hull81_zw(c.x + 2, c.y + 2) : -1;
             if (zw < 0 || c.z != -zw || c.w != zw) is81 = false;
           }
+          // ... and which spline branch a candidate can take (k_scatter_tile81): the home cell must stay at q <= 1,
+          // i.e. h >= (sqrt(3) / 2) d -- the 81-cell hull alone would also admit 0.83 d <= h < 0.866 d
+          if (cfg->particle_kernel_h < 0.8661 * g.d) is81 = false;
           h->std81 = is81 && !env_on("BCHMC_NO_UNROLL");
           // One-pass binning: `cap` record slots per tile = 8x the mean occupancy to start with (the 288 GB of HBM
           // pay for a whole pass over the particles: 3.8 GB of slots at 256^3 fp64), doubled by grow_sort_slots

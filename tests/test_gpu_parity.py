@@ -276,8 +276,13 @@ def test_fp32_field_mode(kw):
     (24, dict(likelihood=0, rsd_model=0)),                       # 8 x 8 x 8 tiles
     (16, dict(likelihood=1, rsd_model=1, particle_kernel_h_rel=1.3)),   # hull not exact: cube loop, halo = reach
     (16, dict(likelihood=1, rsd_model=0, particle_kernel_h_rel=0.8)),   # smaller kernel
+    # the 81-cell hull holds for 0.83 d <= h < 1.06 d, the unrolled kernels' unroll-time choice of spline branch for
+    # 0.866 d <= h only (home cell at q <= 1): just below that bound (generic tile kernel), and inside the range
+    (16, dict(likelihood=1, rsd_model=1, particle_kernel_h_rel=0.85)),
+    (16, dict(likelihood=1, rsd_model=1, particle_kernel_h_rel=0.9)),
+    (16, dict(likelihood=1, rsd_model=0, particle_kernel_h_rel=1.04)),
     (16, dict(likelihood=1, rsd_model=0, min1=1.0, min2=2.0, min3=0.5)),  # xllc != 0: particles below min are dropped
-], ids=["n10_direct", "n12_tile4", "n24_tile8", "h1.3", "h0.8", "xllc"])
+], ids=["n10_direct", "n12_tile4", "n24_tile8", "h1.3", "h0.8", "h0.85", "h0.9", "h1.04", "xllc"])
 def test_other_tilings_and_kernel_sizes(nx, kw):
     import warnings
     c = Case(Nx=nx, **kw)
