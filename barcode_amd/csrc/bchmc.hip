@@ -1036,6 +1036,7 @@ struct Pipe {
         HIPCHK(hipMemcpyAsync(g0_out, h->gk, 2 * (size_t)h->g.Nhp * sizeof(T), hipMemcpyDeviceToDevice, h->stream));
     }
     const void *g_first = g0_in ? g0_in : h->gk;
+    if (neps == 0) return BCHMC_OK;  // HMC.cc:284 loops zero times: the state is returned as it came
 
     const double *wM = h->mass_fs ? h->wM : nullptr;
     const double guard_limit = 1e50 * (double)h->g.N;

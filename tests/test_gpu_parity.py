@@ -68,6 +68,18 @@ def test_forward_model_intermediates(case):
     assert rel_l2(c.e.fetch("deltaX"), dX) < TOL_FIELD
 
 
+def test_zero_step_trajectory_returns_the_state():
+    """Neps = 0 (the reference draws Neps >= 1, HMC.cc:260, but its loop at :284 handles 0): no kick, no drift."""
+    c = Case(Nx=16, likelihood=1, rsd_model=1)
+    e = c.engine()
+    q1, p1, done = e.leapfrog(c.q0, c.p0, c.eps, 0)
+    q1o, p1o, done_o = c.oracle.Hamiltonian_EoM(c.q0, c.p0, c.eps, 0)
+    assert done == done_o == 0
+    assert rel_l2(q1, q1o) < 1e-14 and rel_l2(p1, p1o) < 1e-14
+    assert rel_l2(q1, c.q0) < 1e-14 and rel_l2(p1, c.p0) < 1e-14
+    e.close()
+
+
 def test_positions_wrap_far_outside_the_box():
     """pacman_coordinate (pacman.cpp:20-28) on displacements of many box lengths: the engine folds -L < x < 0 and
     L <= x < 2L with one exact add / subtract and leaves the rest to fmod; every branch must give the oracle's position
