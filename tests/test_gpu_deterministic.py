@@ -76,3 +76,29 @@ def test_deterministic_mode_at_256_cubed():
         res.append((q1, p1))
         e.close()
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+
+
+def test_carried_gradient_is_the_recomputed_one_bit_for_bit(monkeypatch):
+    """In deterministic mode the gradient a chain carries from the end of an accepted trajectory IS the one the next
+    trajectory would evaluate at its start (same state, same kernels, same order): the chain with the carry and the
+    chain that re-evaluates (BCHMC_NO_FORCE_CARRY=1) produce identical bits, planes mode included (32^3 with padding)."""
+    monkeypatch.setenv("BCHMC_FFT_PAD", "1")
+    c = Case(Nx=32, likelihood=1, rsd_model=1)
+    outs = []
+    for no_carry in ("0", "1"):
+        monkeypatch.setenv("BCHMC_NO_FORCE_CARRY", no_carry)
+        e = _engine(c)
+        e.chain_set_state(c.q0)
+        seq = []
+        for i, acc in enumerate([True, False, True, True]):
+            e.chain_draw_momenta(99, i)
+            dH, terms, done = e.chain_attempt(c.eps, 3)
+            q1, p1 = e.chain_get_proposal()
+            seq.append((dH, terms.copy(), q1, p1))
+            e.chain_accept(acc)
+        seq.append((0., np.zeros(6), e.chain_get_state(), e.chain_get_momenta()))
+        outs.append(seq)
+        e.close()
+    for (dH_a, t_a, q_a, p_a), (dH_b, t_b, q_b, p_b) in zip(*outs):
+        assert dH_a == dH_b and np.array_equal(t_a, t_b)
+        assert np.array_equal(q_a, q_b) and np.array_equal(p_a, p_b)
