@@ -757,6 +757,9 @@ __host__ __device__ constexpr int hull81_zw(int a, int b) {
 #ifndef BCHMC_SCATTER_WAVES
 #define BCHMC_SCATTER_WAVES 6
 #endif
+#ifndef BCHMC_GATHER_LEAN
+#define BCHMC_GATHER_LEAN 1
+#endif
 #ifndef BCHMC_GATHER_WAVES
 #define BCHMC_GATHER_WAVES 5
 #endif
@@ -908,6 +911,16 @@ k_gather_tile81(Geo g, HullPar hp, TilePar tp, int rsd, const RecQuad *__restric
     const bool home_ok = (unsigned)(hx - 2) < (unsigned)tp.tx && (unsigned)(hy - 2) < (unsigned)tp.ty &&
                          (unsigned)(hz - 2) < (unsigned)tp.tz;  // always true; keeps LDS indexing safe
     if (home_ok) {
+#if BCHMC_GATHER_LEAN
+      // offsets only: their squares enter through fused multiply-adds where the sums are formed (an add becomes an
+      // fma, no instruction more), which frees the 20 registers of the y and z squares: 6 waves per SIMD without spills
+      T yh[5], zh[5];
+#pragma unroll
+      for (int a = 0; a < 5; a++) {
+        yh[a] = dpcy - (T)(a - 2) * d_h;
+        zh[a] = dpcz - (T)(a - 2) * d_h;
+      }
+#else
       T xh[5], yh[5], zh[5], X[5], Y[5], Z[5];
 #pragma unroll
       for (int a = 0; a < 5; a++) {
@@ -918,15 +931,26 @@ k_gather_tile81(Geo g, HullPar hp, TilePar tp, int rsd, const RecQuad *__restric
         Y[a] = yh[a] * yh[a];
         Z[a] = zh[a] * zh[a];
       }
+#endif
       const T c225n = T(2.25) * norm, c3n = T(-3) * norm, c34n = T(-0.75) * norm;
       const T *corner = s_tile_pl + LZ * ((hy - 2) + LY * (hx - 2)) + (hz - 2);
 #pragma unroll
       for (int a = 0; a < 5; a++) {
+#if BCHMC_GATHER_LEAN
+        const T xh_a = dpcx - (T)(a - 2) * d_h;
+        const T X_a = r_fma(xh_a, xh_a, tiny_pos<T>());  // q^2 > 0 also for a particle exactly on a cell centre
+#else
+        const T xh_a = xh[a], X_a = X[a];
+#endif
 #pragma unroll
         for (int b = 0; b < 5; b++) {
           const int zw = hull81_zw(a, b);  // folds after unrolling
           if (zw < 0) continue;
-          const T r2ab = X[a] + Y[b];
+#if BCHMC_GATHER_LEAN
+          const T r2ab = r_fma(yh[b], yh[b], X_a);
+#else
+          const T r2ab = X_a + Y[b];
+#endif
           if (r2ab > T(4)) continue;
           const T *row = corner + LZ * (b + LY * a);
           // the column's part_like values first: their LDS latency hides behind the first candidate's arithmetic
@@ -938,7 +962,11 @@ k_gather_tile81(Geo g, HullPar hp, TilePar tp, int rsd, const RecQuad *__restric
 #pragma unroll
           for (int c = 0; c < 5; c++) {
             if (c < 2 - zw || c > 2 + zw) continue;
+#if BCHMC_GATHER_LEAN
+            const T q_sq = r_fma(zh[c], zh[c], r2ab);
+#else
             const T q_sq = r2ab + Z[c];
+#endif
             if (q_sq <= T(4)) {
               // grad_SPH_kernel_3D_h_units (SPH_kernel.cpp:148-208): dW/dq / q
               T rq;
@@ -956,7 +984,7 @@ k_gather_tile81(Geo g, HullPar hp, TilePar tp, int rsd, const RecQuad *__restric
                 gr = far ? outer : ((q_sq > T(1)) ? outer : r_fma(c225n, q, c3n));
               }
               const T common = pl[c] * gr;
-              vx += common * xh[a];
+              vx += common * xh_a;
               vy += common * yh[b];
               vz += common * zh[c];
             }
