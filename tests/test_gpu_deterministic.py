@@ -83,6 +83,9 @@ def test_carried_gradient_is_the_recomputed_one_bit_for_bit(monkeypatch):
     trajectory would evaluate at its start (same state, same kernels, same order): the chain with the carry and the
     chain that re-evaluates (BCHMC_NO_FORCE_CARRY=1) produce identical bits, planes mode included (32^3 with padding)."""
     monkeypatch.setenv("BCHMC_FFT_PAD", "1")
+    # the identity needs the trajectory's last force evaluation and a fresh first one to run the same kernels: true
+    # with planes mode at the ends (the default) and without planes mode, not with planes mode for interior steps only
+    monkeypatch.delenv("BCHMC_NO_PLANES_ENDS", raising=False)
     c = Case(Nx=32, likelihood=1, rsd_model=1)
     outs = []
     for no_carry in ("0", "1"):
