@@ -68,6 +68,7 @@ struct bchmc_handle {
   void *V = nullptr;                                 // 3 N: V components
   void *rho = nullptr, *plike = nullptr;             // N each
   long long *rho_fix = nullptr;                      // N: fixed-point density (deterministic mode only)
+  int *fix_sat = nullptr;                            // 1: set by k_fix_to_rho when a fixed-point cell came near wrapping
   bool fix = false;                                  // deterministic mode
   void *ioq = nullptr, *iop = nullptr;               // N each: staging / scratch
   void *gprior = nullptr, *glike = nullptr;          // N each, lazily allocated by bchmc_gradient
@@ -92,13 +93,6 @@ struct bchmc_handle {
   double *h_part = nullptr;                          // pinned host staging for partials
   double *spec_bins = nullptr;                       // measure_spectrum's 3 * n_bin accumulators
   size_t spec_cap = 0;
-  // delta_Hamiltonian of the last bchmc_leapfrog, answered without transfers when asked about the same host arrays
-  struct {
-    bool valid = false;
-    const double *ptr[4] = {nullptr, nullptr, nullptr, nullptr};  // q0, p0, q1, p1 as passed to bchmc_leapfrog
-    uint64_t print[4] = {0, 0, 0, 0};                            // fingerprints of their contents
-    double terms[6] = {0, 0, 0, 0, 0, 0};
-  } last_dh;
   // host-array entry points: caller arrays are pageable, so they cross PCIe through two pinned staging chunks
   // (N-thread memcpy into one chunk while the DMA of the other is in flight)
   void *stg[2] = {nullptr, nullptr};
@@ -376,8 +370,9 @@ int grow_sort_slots(bchmc_handle *h);
 // not inside the next trajectory (reallocating several GB takes between a few and a few hundred milliseconds).
 int read_ctl(bchmc_handle *h, unsigned long long *steps_done) {
   unsigned long long sd = 0;
-  int seen = 0;
+  int seen = 0, sat = 0;
   if (steps_done) HIPCHK(hipMemcpyAsync(&sd, h->steps_done, sizeof sd, hipMemcpyDeviceToHost, h->stream));
+  if (h->fix_sat) HIPCHK(hipMemcpyAsync(&sat, h->fix_sat, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   if (h->tiled && h->sort_direct)
     HIPCHK(hipMemcpyAsync(&seen, h->t_cnt + (kOct + 1) * (size_t)h->tp.ntiles + 1, sizeof(int), hipMemcpyDeviceToHost,
                           h->stream));
@@ -386,6 +381,12 @@ int read_ctl(bchmc_handle *h, unsigned long long *steps_done) {
   if (seen) {
     h->ovf_seen = true;
     CHK(grow_sort_slots(h));
+  }
+  if (sat) {
+    HIPCHK(hipMemsetAsync(h->fix_sat, 0, sizeof(int), h->stream));
+    return h->fail(BCHMC_ERR_STATE,
+                   "deterministic mode: a density cell exceeded the fixed-point range (more than 2^16 maximal "
+                   "contributions in one cell); the results since the last read-back are not valid");
   }
   return BCHMC_OK;
 }
@@ -762,7 +763,8 @@ struct Pipe {
       }
       HIPCHK(hipGetLastError());
       if (h->fix) {
-        k_fix_to_rho<T><<<kRedBlocks, 256, 0, h->stream>>>(h->g.N, h->rho_fix, 1. / fix_scale, R(h->rho), h->rho_part);
+        k_fix_to_rho<T><<<kRedBlocks, 256, 0, h->stream>>>(h->g.N, h->rho_fix, 1. / fix_scale, R(h->rho), h->rho_part,
+                                                           h->fix_sat);
         HIPCHK(hipGetLastError());
       }
     }
@@ -1499,6 +1501,10 @@ struct Pipe {
     if (e_ != hipSuccess) return (h)->fail(BCHMC_ERR_HIP, "hipSetDevice(%d): %s", (h)->c.device, hipGetErrorString(e_)); \
   } while (0)
 
+// A host entry point is about to overwrite (qk, pk, gk): a resident-chain proposal left there by bchmc_chain_attempt
+// is gone, and bchmc_chain_accept / bchmc_chain_get_proposal must say so instead of committing the wrong arrays.
+void clobber_proposal(bchmc_handle *h) { h->have_prop = h->prop_g_valid = false; }
+
 int validate_config(const bchmc_config *c, std::string &why) {
   char buf[256];
   if (c->abi_version != BCHMC_ABI_VERSION) {
@@ -1729,6 +1735,7 @@ int bchmc_create(const bchmc_config *cfg, bchmc_handle **out) {
     CHK(dev_alloc_bytes(h, &h->rho, N * e));
     CHK(dev_alloc_bytes(h, &h->plike, N * e));
     if (h->fix) CHK(dev_alloc(h, &h->rho_fix, N));
+    if (h->fix) CHK(dev_alloc(h, &h->fix_sat, (size_t)1));
     CHK(dev_alloc_bytes(h, &h->ioq, N * e));
     CHK(dev_alloc_bytes(h, &h->iop, N * e));
     CHK(dev_alloc(h, &h->dstage, 2 * N));
@@ -1842,7 +1849,7 @@ void bchmc_destroy(bchmc_handle *h) {
   if (h->info) rocfft_execution_info_destroy(h->info);
   void *ptrs[] = {h->work,  h->wS,       h->wM,    h->qk,    h->pk,   h->gk,     h->Ck,         h->tC,   h->psi,
                   h->V,     h->rho,      h->plike, h->ioq,   h->iop,  h->gprior, h->glike,      h->conv, h->convF,
-                  h->dstage, h->rho_fix, h->spec_bins, h->cq, h->cp, h->cg, h->qk2, h->pk2, h->xtw, h->part6, h->rho_part, h->partA, h->guard, h->stop, h->steps_done, h->hull,  h->t_cnt, h->t_off,
+                  h->dstage, h->rho_fix, h->fix_sat, h->spec_bins, h->cq, h->cp, h->cg, h->qk2, h->pk2, h->xtw, h->part6, h->rho_part, h->partA, h->guard, h->stop, h->steps_done, h->hull,  h->t_cnt, h->t_off,
                   h->t_woff, h->t_oct, h->t_seg, h->t_end, h->t_rank,  h->srec};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
@@ -1887,6 +1894,7 @@ int bchmc_leapfrog_device(bchmc_handle *h, const double *d_q0, const double *d_p
                           double eps, uint64_t neps) {
   if (!h || !d_q0 || !d_p0 || !d_q1 || !d_p1) return BCHMC_ERR_ARG;
   ENTER(h);
+  clobber_proposal(h);
   return DISPATCH(h, leapfrog_core(h, d_q0, d_p0, d_q1, d_p1, eps, neps));
 }
 
@@ -1899,64 +1907,60 @@ int bchmc_steps_done(bchmc_handle *h, uint64_t *steps_done) {
   return BCHMC_OK;
 }
 
-// Content fingerprint of a host array: 509 samples spread over it + both ends (FNV-1a over their bit patterns).
-// Decides whether bchmc_delta_hamiltonian is being asked about the arrays of the last bchmc_leapfrog, unchanged.
-static uint64_t host_fingerprint(const double *a, size_t n) {
-  uint64_t hsh = 1469598103934665603ull;
-  auto mix = [&](double v) {
-    uint64_t b;
-    std::memcpy(&b, &v, sizeof b);
-    hsh = (hsh ^ b) * 1099511628211ull;
-  };
-  const size_t stride = std::max<size_t>(n / 509, 1);
-  for (size_t i = 0; i < n; i += stride) mix(a[i]);
-  mix(a[n - 1]);
-  return hsh;
-}
-
 int bchmc_leapfrog(bchmc_handle *h, const double *q0, const double *p0, double *q1, double *p1, double eps,
                    uint64_t neps, uint64_t *steps_done) {
   if (!h || !q0 || !p0 || !q1 || !p1) return BCHMC_ERR_ARG;
   ENTER(h);
+  clobber_proposal(h);
   const size_t N = (size_t)h->g.N, bytes = N * sizeof(double);
   double *dq = h->dstage, *dp = h->dstage + N;
-  h->last_dh.valid = false;
+  CHK(h2d(h, dq, q0, bytes));
+  CHK(h2d(h, dp, p0, bytes));
+  CHK(DISPATCH(h, leapfrog_core(h, dq, dp, dq, dp, eps, neps)));
+  CHK(d2h(h, q1, dq, bytes));
+  CHK(d2h(h, p1, dp, bytes));
+  uint64_t done = 0;
+  CHK(bchmc_steps_done(h, &done));
+  if (steps_done) *steps_done = done;
+  return BCHMC_OK;
+}
+
+int bchmc_leapfrog_dh(bchmc_handle *h, const double *q0, const double *p0, double *q1, double *p1, double eps,
+                      uint64_t neps, uint64_t *steps_done, double *dH, double terms[6]) {
+  if (!h || !q0 || !p0 || !q1 || !p1 || !dH || !terms) return BCHMC_ERR_ARG;
+  ENTER(h);
+  clobber_proposal(h);
+  const size_t N = (size_t)h->g.N, bytes = N * sizeof(double);
+  double *dq = h->dstage, *dp = h->dstage + N;
   CHK(h2d(h, dq, q0, bytes));
   CHK(h2d(h, dp, p0, bytes));
   uint64_t done = 0;
-  double terms[6];
-  const bool with_dh = neps >= 1 && !env_on("BCHMC_NO_DH_CACHE");
-  if (with_dh) {
-    CHK(DISPATCH(h, leapfrog_host_core(h, eps, neps, terms, &done)));
-  } else {
-    CHK(DISPATCH(h, leapfrog_core(h, dq, dp, dq, dp, eps, neps)));
-  }
+  // one pass: the trajectory's own first and last force evaluation carry -log L of both ends, K and psi_prior are
+  // Parseval sums of the k-space state (the resident chain's attempt_core); generic configurations evaluate the
+  // energies around the trajectory without further transfers
+  CHK(DISPATCH(h, leapfrog_host_core(h, eps, neps, terms, &done)));
   CHK(d2h(h, q1, dq, bytes));
   CHK(d2h(h, p1, dp, bytes));
-  if (with_dh) {
-    const double *ptr[4] = {q0, p0, q1, p1};
-    for (int i = 0; i < 4; i++) {
-      h->last_dh.ptr[i] = ptr[i];
-      h->last_dh.print[i] = host_fingerprint(ptr[i], N);
-      }
-    std::memcpy(h->last_dh.terms, terms, sizeof terms);
-    h->last_dh.valid = true;
-  } else {
-    CHK(bchmc_steps_done(h, &done));
-  }
   if (steps_done) *steps_done = done;
+  const double Hami = terms[0] + (terms[1] + terms[2]);
+  const double Hamf = terms[3] + (terms[4] + terms[5]);
+  double d = Hamf - Hami;
+  if (h->c.div_dH_by_N) d /= (double)h->g.N;  // HMC.cc:234-237
+  *dH = d;
   return BCHMC_OK;
 }
 
 int bchmc_energies_device(bchmc_handle *h, const double *d_q, const double *d_p, double out[3]) {
   if (!h || !d_q || !d_p || !out) return BCHMC_ERR_ARG;
   ENTER(h);
+  clobber_proposal(h);
   return DISPATCH(h, energies_core(h, d_q, d_p, out));
 }
 
 int bchmc_energies(bchmc_handle *h, const double *q, const double *p, double out[3]) {
   if (!h || !q || !p || !out) return BCHMC_ERR_ARG;
   ENTER(h);
+  clobber_proposal(h);
   const size_t N = (size_t)h->g.N, bytes = N * sizeof(double);
   CHK(h2d(h, h->dstage, q, bytes));
   CHK(h2d(h, h->dstage + N, p, bytes));
@@ -1967,6 +1971,7 @@ int bchmc_energies(bchmc_handle *h, const double *q, const double *p, double out
 int bchmc_kinetic_term(bchmc_handle *h, const double *p, double *out) {
   if (!h || !p || !out) return BCHMC_ERR_ARG;
   ENTER(h);
+  clobber_proposal(h);
   CHK(h2d(h, h->dstage + (size_t)h->g.N, p, (size_t)h->g.N * sizeof(double)));
   return DISPATCH(h, kinetic_core(h, h->dstage + (size_t)h->g.N, out));
 }
@@ -1974,6 +1979,7 @@ int bchmc_kinetic_term(bchmc_handle *h, const double *p, double *out) {
 int bchmc_psi(bchmc_handle *h, const double *q, double out[2]) {
   if (!h || !q || !out) return BCHMC_ERR_ARG;
   ENTER(h);
+  clobber_proposal(h);
   CHK(h2d(h, h->dstage, q, (size_t)h->g.N * sizeof(double)));
   CHK(DISPATCH(h, psi_core(h, h->dstage, out)));
   return read_ctl(h, nullptr);
@@ -1982,19 +1988,10 @@ int bchmc_psi(bchmc_handle *h, const double *q, double out[2]) {
 int bchmc_delta_hamiltonian(bchmc_handle *h, const double *qi, const double *pi, const double *qf, const double *pf,
                             double *dH, double terms[6]) {
   if (!h || !dH || !terms || !qi || !pi || !qf || !pf) return BCHMC_ERR_ARG;
-  // HamiltonianMC asks this right after Hamiltonian_EoM, about the same four arrays (HMC.cc:455-459): the single
-  // pass of bchmc_leapfrog has produced the six terms already (like bchmc_chain_attempt does), and the forward model
-  // left in the handle is psi(signalf)'s, as after the reference's evaluation order (HMC.cc:225)
-  bool cached = h->last_dh.valid;
-  const double *ptr[4] = {qi, pi, qf, pf};
-  for (int i = 0; cached && i < 4; i++)
-    cached = ptr[i] == h->last_dh.ptr[i] && host_fingerprint(ptr[i], (size_t)h->g.N) == h->last_dh.print[i];
-  if (cached) {
-    std::memcpy(terms, h->last_dh.terms, 6 * sizeof(double));
-  } else {
-    CHK(bchmc_energies(h, qi, pi, terms));
-    CHK(bchmc_energies(h, qf, pf, terms + 3));
-  }
+  // always evaluated: kinetic_term + psi at both ends, HMC.cc:214-225, psi(signalf) last.  A caller that has just run
+  // the trajectory on these arrays gets the same six terms from bchmc_leapfrog_dh without the four uploads.
+  CHK(bchmc_energies(h, qi, pi, terms));
+  CHK(bchmc_energies(h, qf, pf, terms + 3));
   const double Hami = terms[0] + (terms[1] + terms[2]);
   const double Hamf = terms[3] + (terms[4] + terms[5]);
   double d = Hamf - Hami;
@@ -2006,6 +2003,7 @@ int bchmc_delta_hamiltonian(bchmc_handle *h, const double *qi, const double *pi,
 int bchmc_forward(bchmc_handle *h, const double *q, int use_rsd) {
   if (!h || !q) return BCHMC_ERR_ARG;
   ENTER(h);
+  clobber_proposal(h);
   CHK(h2d(h, h->dstage, q, h->g.N * sizeof(double)));
   CHK(DISPATCH(h, forward(h, h->dstage, use_rsd < 0 ? h->c.rsd_model : (use_rsd ? 1 : 0))));
   return read_ctl(h, nullptr);  // synchronises; enlarges the binning's record slots if this field overflowed them
@@ -2014,6 +2012,7 @@ int bchmc_forward(bchmc_handle *h, const double *q, int use_rsd) {
 int bchmc_gradient(bchmc_handle *h, const double *q, double *gout) {
   if (!h || !q || !gout) return BCHMC_ERR_ARG;
   ENTER(h);
+  clobber_proposal(h);
   CHK(check_inputs(h));
   const size_t N = (size_t)h->g.N;
   CHK(h2d(h, h->dstage, q, N * sizeof(double)));

@@ -159,12 +159,33 @@ void bchmc_comm_destroy(bchmc_comm *c) {
 }
 
 int bchmc_comm_pending(const bchmc_comm *c) { return c ? (int)c->queue.size() : 0; }
+int bchmc_comm_world(const bchmc_comm *c) { return c ? c->world : 0; }
+int bchmc_comm_rank(const bchmc_comm *c) { return c ? c->rank : -1; }
+const char *bchmc_comm_transport(const bchmc_comm *c) {
+  if (!c) return "";
+  if (c->comm) return "rccl";
+  return c->fn ? "custom" : "none";  // "none": a one-rank communicator without a transport
+}
 
 int bchmc_eps_exchange(bchmc_comm *c, const bchmc_eps_record *mine, int n_mine, bchmc_eps_record *all, int *rank_of,
                        int cap, int *n_all) {
   if (!c || !all || !n_all || n_mine < 0 || (n_mine > 0 && !mine) || cap < 0) return BCHMC_ERR_ARG;
   *n_all = 0;
+  // every argument and state check comes before anything is queued or sent: a call that fails has no effect on this
+  // rank (its records are NOT kept: retry with the same `mine`), and one that could fail after the collective ran
+  // would leave the peers holding records this rank reports as unsent
+  if ((long long)cap < (long long)c->world * BCHMC_EPS_BATCH)
+    return c->fail(BCHMC_ERR_ARG, "output capacity " + std::to_string(cap) + " < world * BCHMC_EPS_BATCH = " +
+                                      std::to_string((long long)c->world * BCHMC_EPS_BATCH));
+  if (c->world > 1 && !c->fn && !c->comm) return c->fail(BCHMC_ERR_STATE, "communicator was not initialised");
   for (int i = 0; i < n_mine; i++) c->queue.push_back(mine[i]);
+  struct Unqueue {  // failure below: take this call's records back out
+    std::deque<bchmc_eps_record> &q;
+    int n;
+    ~Unqueue() {
+      for (int i = 0; i < n; i++) q.pop_back();
+    }
+  } unqueue{c->queue, n_mine};
   Packet send;
   std::memset(&send, 0, sizeof send);
   send.n = (int32_t)std::min<size_t>(c->queue.size(), BCHMC_EPS_BATCH);
@@ -189,14 +210,12 @@ int bchmc_eps_exchange(bchmc_comm *c, const bchmc_eps_record *mine, int n_mine, 
     std::memcpy(c->recv.data(), c->h_pin + 1, sizeof(Packet) * (size_t)c->world);
   }
   // validate before consuming: a transport that scribbles must not turn into an out-of-bounds read here
-  int total = 0;
   for (int rk = 0; rk < c->world; rk++) {
-    const int n = c->recv[(size_t)rk].n;
+    const int n = c->recv[(size_t)rk].n;  // <= BCHMC_EPS_BATCH each: the sum fits `cap` (checked above)
     if (n < 0 || n > BCHMC_EPS_BATCH) return c->fail(BCHMC_ERR_STATE, "malformed packet from rank " + std::to_string(rk));
-    total += n;
   }
   if (c->recv[(size_t)c->rank].n != send.n) return c->fail(BCHMC_ERR_STATE, "own packet came back altered");
-  if (total > cap) return c->fail(BCHMC_ERR_ARG, "output capacity " + std::to_string(cap) + " < " + std::to_string(total));
+  unqueue.n = 0;                                          // the exchange happened: this call's records stay queued / sent
   for (int i = 0; i < send.n; i++) c->queue.pop_front();  // sent: every rank now holds them
   int k = 0;
   for (int rk = 0; rk < c->world; rk++)

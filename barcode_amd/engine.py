@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must precede loading libbarcode_hip.so, see module 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # BCHMC_LIB: an alternative build of the same library (A/B runs of kernel variants on one box)
 LIB_PATH = os.environ.get("BCHMC_LIB") or os.path.join(_HERE, "libbarcode_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 FIELDS = dict(signal_PS=0, mass_f=1, mass_r=2, nobs=3, noise=4, window=5, deltaX=6, posx=7, posy=8, posz=9,
               rho=10, part_like=11, Vx=12, Vy=13, Vz=14, psix=15, psiy=16, psiz=17, grad_prior=18, grad_like=19)
@@ -64,14 +64,15 @@ _lib = None
 
 # every symbol include/bchmc.h declares; tests check that the library exports all of them
 EXPORTS = ("bchmc_create", "bchmc_destroy", "bchmc_strerror", "bchmc_last_error", "bchmc_upload", "bchmc_fetch",
-           "bchmc_leapfrog", "bchmc_energies", "bchmc_delta_hamiltonian", "bchmc_gradient", "bchmc_forward",
+           "bchmc_leapfrog", "bchmc_leapfrog_dh", "bchmc_energies", "bchmc_delta_hamiltonian", "bchmc_gradient", "bchmc_forward",
            "bchmc_leapfrog_device", "bchmc_steps_done", "bchmc_energies_device", "bchmc_sync", "bchmc_stream",
            "bchmc_profile", "bchmc_profile_read", "bchmc_kernel_name",
            "bchmc_chain_set_state", "bchmc_chain_get_state", "bchmc_chain_set_momenta", "bchmc_chain_get_momenta",
            "bchmc_chain_draw_momenta", "bchmc_chain_attempt", "bchmc_chain_get_proposal", "bchmc_chain_accept",
            "bchmc_measure_spectrum", "bchmc_philox_kat", "bchmc_kinetic_term", "bchmc_psi",
            "bchmc_comm_unique_id", "bchmc_comm_create", "bchmc_comm_create_custom", "bchmc_comm_destroy",
-           "bchmc_comm_last_error", "bchmc_eps_exchange", "bchmc_comm_pending")
+           "bchmc_comm_last_error", "bchmc_eps_exchange", "bchmc_comm_pending", "bchmc_comm_world", "bchmc_comm_rank",
+           "bchmc_comm_transport")
 
 
 def load():
@@ -94,6 +95,7 @@ def load():
     lib.bchmc_upload.argtypes = [vp, C.c_int, dp, C.c_size_t]
     lib.bchmc_fetch.argtypes = [vp, C.c_int, dp, C.c_size_t]
     lib.bchmc_leapfrog.argtypes = [vp, dp, dp, dp, dp, C.c_double, u64, C.POINTER(u64)]
+    lib.bchmc_leapfrog_dh.argtypes = [vp, dp, dp, dp, dp, C.c_double, u64, C.POINTER(u64), dp, dp]
     lib.bchmc_energies.argtypes = [vp, dp, dp, dp]
     lib.bchmc_delta_hamiltonian.argtypes = [vp, dp, dp, dp, dp, dp, dp]
     lib.bchmc_gradient.argtypes = [vp, dp, dp]
@@ -130,6 +132,10 @@ def load():
     lib.bchmc_eps_exchange.argtypes = [vp, C.POINTER(EpsRecord), C.c_int, C.POINTER(EpsRecord), C.POINTER(C.c_int),
                                        C.c_int, C.POINTER(C.c_int)]
     lib.bchmc_comm_pending.argtypes = [vp]
+    lib.bchmc_comm_world.argtypes = [vp]
+    lib.bchmc_comm_rank.argtypes = [vp]
+    lib.bchmc_comm_transport.argtypes = [vp]
+    lib.bchmc_comm_transport.restype = C.c_char_p
     _lib = lib
     return lib
 
@@ -226,6 +232,16 @@ class Engine:
         self._chk(self.lib.bchmc_leapfrog(self.h, _p(self._in(q0)), _p(self._in(p0)), _p(q1), _p(p1), float(eps),
                                           int(neps), C.byref(done)))
         return q1, p1, done.value
+
+    def leapfrog_dh(self, q0, p0, eps, neps, out=None):
+        """Hamiltonian_EoM + delta_Hamiltonian of the same four arrays in one pass (bchmc_leapfrog_dh).
+        Returns (q1, p1, steps_done, dH, terms[6])."""
+        q1, p1 = out if out is not None else (np.empty(self.N), np.empty(self.N))
+        done, dH = C.c_uint64(), C.c_double()
+        terms = np.zeros(6)
+        self._chk(self.lib.bchmc_leapfrog_dh(self.h, _p(self._in(q0)), _p(self._in(p0)), _p(q1), _p(p1), float(eps),
+                                             int(neps), C.byref(done), C.byref(dH), _p(terms)))
+        return q1, p1, done.value, dH.value, terms
 
     def kinetic_term(self, p):
         out = C.c_double()
@@ -393,6 +409,11 @@ class Comm:
 
     def pending(self):
         return int(self.lib.bchmc_comm_pending(self.h))
+
+    def info(self):
+        """What the communicator itself reports (not what the caller asked for): world, rank, transport."""
+        return dict(world=int(self.lib.bchmc_comm_world(self.h)), rank=int(self.lib.bchmc_comm_rank(self.h)),
+                    transport=self.lib.bchmc_comm_transport(self.h).decode())
 
     def close(self):
         if getattr(self, "h", None):

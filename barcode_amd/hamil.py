@@ -69,7 +69,10 @@ def Hamiltonian_EoM(hd, signali, momentai, uniform):
     n.epsilon = float(n.eps_fac * uniform())
     if n.epsilon > 2.0:
         n.epsilon = 2.0
-    signalf, momentaf, done = hd.engine.leapfrog(signali, momentai, n.epsilon, n.Neps)
+    # one pass: the trajectory and the six energy terms of its four arrays (bchmc_leapfrog_dh), kept for the
+    # delta_Hamiltonian that HamiltonianMC calls next about the same arrays (HMC.cc:455-459; the C++ shim does the same)
+    signalf, momentaf, done, dH, t = hd.engine.leapfrog_dh(signali, momentai, n.epsilon, n.Neps)
+    hd._eom = ((signali, momentai, signalf, momentaf), dH, t)
     n.steps_done = done
     n.count_attempts += 1  # data->numerical->count_attempts++ (HMC.cc:368)
     return signalf, momentaf
@@ -98,7 +101,11 @@ def psi(hd, signal, momenta=None):
 def delta_Hamiltonian(hd, signali, momentai, signalf, momentaf):
     """HMC.cc:209-248, including the performance-log bookkeeping."""
     n = hd.numerical
-    dH, t = hd.engine.delta_hamiltonian(signali, momentai, signalf, momentaf)
+    kept, hd._eom = getattr(hd, "_eom", None), None  # one use, only as the next call about the very same arrays
+    if kept is not None and all(a is b for a, b in zip(kept[0], (signali, momentai, signalf, momentaf))):
+        dH, t = kept[1], kept[2]
+    else:
+        dH, t = hd.engine.delta_hamiltonian(signali, momentai, signalf, momentaf)
     n.H_kin_i, n.psi_prior_i, n.psi_likeli_i = (float(x) for x in t[:3])
     n.H_kin_f, n.psi_prior_f, n.psi_likeli_f = (float(x) for x in t[3:])
     n.psi_prior, n.psi_likeli = n.psi_prior_f, n.psi_likeli_f

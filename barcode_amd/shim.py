@@ -23,7 +23,8 @@ SHIM_EXPORTS = ("bchmc_shim_Hamiltonian_EoM", "bchmc_shim_delta_Hamiltonian", "b
                 "bchmc_shim_eps_create", "bchmc_shim_eps_destroy", "bchmc_shim_eps_append", "bchmc_shim_eps_records",
                 "bchmc_shim_eps_acceptance_rate", "bchmc_shim_update_eps_fac", "bchmc_shim_update_tables",
                 "bchmc_shim_comm_bootstrap_file", "bchmc_shim_comm_attach", "bchmc_shim_comm_release",
-                "bchmc_shim_inputs_changed", "bchmc_shim_mass_changed")
+                "bchmc_shim_inputs_changed", "bchmc_shim_mass_changed", "bchmc_shim_bootstrap_exchange_id",
+                "bchmc_shim_bootstrap_cleanup")
 
 _dp = C.POINTER(C.c_double)
 
@@ -48,6 +49,12 @@ class HamilNumericalView(C.Structure):
     ]
 
 
+class EomEnergies(C.Structure):
+    """bchmc_shim::HamilView::EomEnergies: the six terms Hamiltonian_EoM keeps for the delta_Hamiltonian that follows."""
+    _fields_ = [("valid", C.c_bool), ("ptr", _dp * 4), ("hash", C.c_uint64 * 4), ("terms", C.c_double * 6),
+                ("dH", C.c_double), ("inputs_generation", C.c_ulong), ("mass_generation", C.c_ulong)]
+
+
 class HamilView(C.Structure):
     """bchmc_shim::HamilView (members of HAMIL_DATA, struct_hamil.h:146-222)."""
     _fields_ = [
@@ -61,6 +68,7 @@ class HamilView(C.Structure):
         ("eps", C.c_void_p), ("comm", C.c_void_p), ("comm_rank", C.c_int),
         ("inputs_generation", C.c_ulong), ("uploaded_generation", C.c_ulong), ("deterministic", C.c_int),
         ("mass_generation", C.c_ulong), ("mass_uploaded_generation", C.c_ulong),
+        ("reuse_eom_energies", C.c_int), ("eom", EomEnergies),
     ]
 
 
@@ -118,6 +126,10 @@ def load():
     lib.bchmc_shim_update_eps_fac.argtypes = [hv, C.c_char_p, sz, C.c_char_p, sz]
     lib.bchmc_shim_update_tables.argtypes = [hv, C.c_char_p, sz]
     lib.bchmc_shim_comm_bootstrap_file.argtypes = [hv, C.c_char_p, C.c_int, C.c_int, C.c_double, C.c_char_p, sz]
+    lib.bchmc_shim_bootstrap_exchange_id.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_ubyte),
+                                                     C.c_char_p, sz]
+    lib.bchmc_shim_bootstrap_cleanup.argtypes = [C.c_char_p, C.c_int]
+    lib.bchmc_shim_bootstrap_cleanup.restype = None
     lib.bchmc_shim_comm_attach.argtypes = [hv, C.c_void_p, C.c_int]
     lib.bchmc_shim_comm_release.argtypes = [hv]
     lib.bchmc_shim_comm_release.restype = None
@@ -138,6 +150,23 @@ def load():
 
 class ShimError(RuntimeError):
     """The C++ layer threw std::runtime_error."""
+
+
+def bootstrap_exchange_id(path, rank, world, unique_id=None, timeout_s=30.0):
+    """bchmc_shim::bootstrap_exchange_id: the file protocol that carries rank 0's 128-byte id to the other ranks
+    (host only).  Rank 0 passes ``unique_id``; every rank gets the id back."""
+    lib = load()
+    buf = (C.c_ubyte * _engine.UNIQUE_ID_BYTES)()
+    if rank == 0:
+        buf[:] = bytes(unique_id)
+    err = C.create_string_buffer(512)
+    if lib.bchmc_shim_bootstrap_exchange_id(str(path).encode(), int(rank), int(world), float(timeout_s), buf, err, len(err)):
+        raise ShimError(err.value.decode())
+    return bytes(buf)
+
+
+def bootstrap_cleanup(path, rank):
+    load().bchmc_shim_bootstrap_cleanup(str(path).encode(), int(rank))
 
 
 def _p(a):
@@ -177,6 +206,7 @@ class ShimHamil:
             self._keep[k] = a
             setattr(hd, k, _p(a))
         hd.device = device
+        hd.reuse_eom_energies = 1
         self.hd = hd
         self.count_attempts = C.c_ulong(0)
         self._err = C.create_string_buffer(512)
@@ -190,8 +220,8 @@ class ShimHamil:
         assert a.size == self.N
         return a
 
-    def Hamiltonian_EoM(self, signali, momentai, uniform):
-        qf, pf = np.empty(self.N), np.empty(self.N)
+    def Hamiltonian_EoM(self, signali, momentai, uniform, out=None):
+        qf, pf = out if out is not None else (np.empty(self.N), np.empty(self.N))
         done = C.c_ulong(0)
         cb = UNIFORM_FN(lambda _state: float(uniform()))
         self._chk(self.lib.bchmc_shim_Hamiltonian_EoM(C.byref(self.hd), _p(self._in(signali)), _p(self._in(momentai)),

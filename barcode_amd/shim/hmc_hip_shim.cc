@@ -4,10 +4,12 @@
 
 #include <unistd.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <random>
 #include <thread>
 #include <vector>
 
@@ -33,8 +35,45 @@ void upload_inputs(HamilView *hd, bchmc_handle *h) {
     }
 }
 
-bchmc_handle *engine_for(HamilView *hd) {
+// 64-bit content hash of a host array (reuse_eom_energies == 2): four interleaved multiply-xorshift lanes per thread,
+// several threads; every word enters, so a single changed element changes the hash (up to 2^-64 collisions).
+std::uint64_t content_hash(const real_prec *a, ULONG n) {
+  const unsigned nt = std::max(1u, std::min(8u, std::thread::hardware_concurrency() / 2));
+  std::vector<std::uint64_t> part(nt, 0);
+  auto work = [&](unsigned t) {
+    const ULONG lo = n * t / nt, hi = n * (t + 1) / nt;
+    std::uint64_t l[4] = {0x9E3779B97F4A7C15ull, 0xC2B2AE3D27D4EB4Full, 0x165667B19E3779F9ull, 0x27D4EB2F165667C5ull};
+    ULONG i = lo;
+    auto mix = [](std::uint64_t h, std::uint64_t w) {
+      h = (h ^ w) * 0xFF51AFD7ED558CCDull;
+      return h ^ (h >> 29);
+    };
+    for (; i + 4 <= hi; i += 4) {
+      std::uint64_t w[4];
+      std::memcpy(w, a + i, sizeof w);
+      for (int k = 0; k < 4; k++) l[k] = mix(l[k], w[k]);
+    }
+    for (; i < hi; i++) {
+      std::uint64_t w;
+      std::memcpy(&w, a + i, sizeof w);
+      l[0] = mix(l[0], w);
+    }
+    part[t] = mix(mix(mix(l[0], l[1]), l[2]), l[3]);
+  };
+  std::vector<std::thread> th;
+  for (unsigned t = 1; t < nt; t++) th.emplace_back(work, t);
+  work(0);
+  for (auto &x : th) x.join();
+  std::uint64_t h = n;
+  for (unsigned t = 0; t < nt; t++) h = (h ^ part[t]) * 0xC4CEB9FE1A85EC53ull + t;
+  return h;
+}
+
+// keep_eom: only delta_Hamiltonian may find the energies of the preceding Hamiltonian_EoM; any other call in between
+// ends their validity (it may leave another forward model in the engine, whose deltaX / pos* would be fetched).
+bchmc_handle *engine_for(HamilView *hd, bool keep_eom = false) {
   if (!hd || !hd->numerical) throw std::runtime_error("In hmc_hip_shim: HAMIL_DATA without numerical");
+  if (!keep_eom) hd->eom.valid = false;
   if (hd->engine) {
     bchmc_handle *h = static_cast<bchmc_handle *>(hd->engine);
     if (hd->uploaded_generation != hd->inputs_generation) {  // inputs_changed() since the last upload
@@ -116,8 +155,24 @@ Attempt Hamiltonian_EoM(HamilView *hd, const real_prec *signali, const real_prec
   n->epsilon = static_cast<real_prec>(n->eps_fac * uniform(rng_state));
   if (n->epsilon > 2.) n->epsilon = 2.;
   uint64_t done = 0;
-  const int rc = bchmc_leapfrog(h, signali, momentai, signalf, momentaf, n->epsilon, n->Neps, &done);
-  if (rc) fail(h, rc, "Hamiltonian_EoM");
+  if (hd->reuse_eom_energies) {
+    // trajectory and the six energy terms of its four arrays in one pass, kept for the delta_Hamiltonian that follows
+    HamilView::EomEnergies &e = hd->eom;
+    const int rc = bchmc_leapfrog_dh(h, signali, momentai, signalf, momentaf, n->epsilon, n->Neps, &done, &e.dH, e.terms);
+    if (rc) fail(h, rc, "Hamiltonian_EoM");
+    const real_prec *ptr[4] = {signali, momentai, signalf, momentaf};
+    for (int i = 0; i < 4; i++) {
+      e.ptr[i] = ptr[i];
+      e.hash[i] = hd->reuse_eom_energies >= 2 ? content_hash(ptr[i], n->N) : 0;
+    }
+    e.inputs_generation = hd->inputs_generation;
+    e.mass_generation = hd->mass_generation;
+    // in place (signalf == signali): delta_Hamiltonian will be asked about arrays that no longer hold the start state
+    e.valid = signali != signalf && momentai != momentaf && signali != momentaf && momentai != signalf;
+  } else {
+    const int rc = bchmc_leapfrog(h, signali, momentai, signalf, momentaf, n->epsilon, n->Neps, &done);
+    if (rc) fail(h, rc, "Hamiltonian_EoM");
+  }
   if (count_attempts) ++*count_attempts;  // HMC.cc:368
   Attempt a;
   a.steps_done = static_cast<ULONG>(done);
@@ -126,11 +181,24 @@ Attempt Hamiltonian_EoM(HamilView *hd, const real_prec *signali, const real_prec
 
 real_prec delta_Hamiltonian(HamilView *hd, const real_prec *signali, const real_prec *momentai, const real_prec *signalf,
                             const real_prec *momentaf) {
-  bchmc_handle *h = engine_for(hd);
+  bchmc_handle *h = engine_for(hd, /*keep_eom=*/true);
   HamilNumericalView *n = hd->numerical;
   double dH = 0., t[6];
-  const int rc = bchmc_delta_hamiltonian(h, signali, momentai, signalf, momentaf, &dH, t);
-  if (rc) fail(h, rc, "delta_Hamiltonian");
+  HamilView::EomEnergies &e = hd->eom;
+  const real_prec *ptr[4] = {signali, momentai, signalf, momentaf};
+  bool reuse = hd->reuse_eom_energies && e.valid && e.inputs_generation == hd->inputs_generation &&
+               e.mass_generation == hd->mass_generation;
+  for (int i = 0; reuse && i < 4; i++) reuse = ptr[i] == e.ptr[i];
+  if (reuse && hd->reuse_eom_energies >= 2)
+    for (int i = 0; reuse && i < 4; i++) reuse = content_hash(ptr[i], n->N) == e.hash[i];
+  e.valid = false;  // one use: a second delta_Hamiltonian evaluates
+  if (reuse) {
+    dH = e.dH;
+    std::memcpy(t, e.terms, sizeof t);
+  } else {
+    const int rc = bchmc_delta_hamiltonian(h, signali, momentai, signalf, momentaf, &dH, t);
+    if (rc) fail(h, rc, "delta_Hamiltonian");
+  }
   n->H_kin_i = t[0]; n->psi_prior_i = t[1]; n->psi_likeli_i = t[2];  // HMC.cc:218-245
   n->H_kin_f = t[3]; n->psi_prior_f = t[4]; n->psi_likeli_f = t[5];
   n->psi_prior = t[4]; n->psi_likeli = t[5];                         // psi(signalf) is evaluated last (225)
@@ -222,75 +290,15 @@ ULONG HamiltonianMC_ops(HamilView *hd, const ChainOps &ops, void *engine, unifor
   std::string host_p;
   if (momenta) host_p.resize(n->N * sizeof(real_prec));
   std::vector<bchmc_eps_record> mine;  // this sample's records, exchanged once after the loop
-  ULONG it = 0;
-  while (it < itmax) {  // HMC.cc:431
-    const ULONG attempt = count_attempts ? *count_attempts : it;
-    if (momenta) {  // HMC.cc:445-449 with the caller's generator
-      real_prec *p = reinterpret_cast<real_prec *>(&host_p[0]);
-      momenta(momenta_state, p, n->N);
-      chk(ops.set_momenta(engine, p), "draw_momenta");
-    } else {
-      chk(ops.draw_momenta(engine, seed, attempt), "draw_momenta");
-    }
-    update_eps_fac(hd);  // HMC.cc:453
-    // HMC.cc:260-264
-    n->Neps = static_cast<ULONG>(n->N_eps_fac * uniform(rng_state)) + 1;
-    n->epsilon = static_cast<real_prec>(n->eps_fac * uniform(rng_state));
-    if (n->epsilon > 2.) n->epsilon = 2.;
-    double dH = 0., t[6] = {0., 0., 0., 0., 0., 0.};
-    uint64_t done = 0;
-    chk(ops.attempt(engine, n->epsilon, n->Neps, &dH, t, &done), "Hamiltonian_EoM");
-    if (count_attempts) ++*count_attempts;  // HMC.cc:368
-    n->H_kin_i = t[0]; n->psi_prior_i = t[1]; n->psi_likeli_i = t[2];
-    n->H_kin_f = t[3]; n->psi_prior_f = t[4]; n->psi_likeli_f = t[5];
-    n->psi_prior = t[4]; n->psi_likeli = t[5];
-    n->dprior = t[4] - t[1];
-    n->dlikeli = t[5] - t[2];
-    n->dK = t[3] - t[0];
-    n->dE = n->dprior + n->dlikeli;
-    n->dH = dH;
-    // HMC.cc:462-486
-    real_prec p_acceptance = 1.;
-    if (dH < 0.)
-      p_acceptance = 1.;
-    else if (std::exp(-dH) < 1.)
-      p_acceptance = std::exp(-dH);
-    bool accepted;
-    if (p_acceptance >= 1.)
-      accepted = true;
-    else
-      accepted = uniform(rng_state) < p_acceptance;
-    chk(ops.accept(engine, accepted ? 1 : 0), "chain_accept");  // HMC.cc:497-498
-    if (!accepted) n->rejections++;                              // HMC.cc:500-501
-    n->accepted = accepted;                                      // HMC.cc:503-504
-    if (log && it < log_cap) {                                   // write_to_performance_log's row, HMC.cc:506
-      AttemptLog &r = log[it];
-      r.accepted = accepted;
-      r.epsilon = n->epsilon;
-      r.Neps = n->Neps;
-      r.steps_done = static_cast<ULONG>(done);
-      r.dH = dH; r.dK = n->dK; r.dE = n->dE; r.dprior = n->dprior; r.dlikeli = n->dlikeli;
-      r.psi_prior_i = t[1]; r.psi_prior_f = t[4]; r.psi_likeli_i = t[2]; r.psi_likeli_f = t[5];
-      r.H_kin_i = t[0]; r.H_kin_f = t[3];
-    }
-    update_epsilon_acc_rate_tables(hd);  // HMC.cc:507
-    if (hd->comm) {
-      bchmc_eps_record rec;
-      rec.epsilon = n->epsilon;
-      rec.accepted = accepted ? 1 : 0;
-      rec.neps = static_cast<int32_t>(n->Neps);
-      mine.push_back(rec);
-    }
-    ++it;
-    if (accepted) break;
-  }
-  if (hd->comm) {
-    // the fixed point every chain reaches once per sample: pool the step-size statistics
-    const int cap = 64 * BCHMC_EPS_BATCH;
+  // the fixed point every chain reaches once per sample: pool the step-size statistics.  Also reached when
+  // the attempt loop throws (an engine error): the other ranks are waiting in their all-gather, so this rank takes part
+  // with what it has and reports its own error afterwards instead of leaving them blocked until the RCCL timeout.
+  auto exchange = [&]() {
+    if (!hd->comm) return;
+    const int cap = std::max(1, bchmc_comm_world(hd->comm)) * BCHMC_EPS_BATCH;
     std::vector<bchmc_eps_record> all(static_cast<size_t>(cap));
     std::vector<int> rank_of(static_cast<size_t>(cap));
     int n_all = 0;
-    // a communicator of more than 64 ranks would need a larger buffer; one node has 8
     const int rc = bchmc_eps_exchange(hd->comm, mine.data(), static_cast<int>(mine.size()), all.data(), rank_of.data(),
                                       cap, &n_all);
     if (rc) throw std::runtime_error(std::string("In bchmc_eps_exchange: ") + bchmc_comm_last_error(hd->comm));
@@ -298,38 +306,209 @@ ULONG HamiltonianMC_ops(HamilView *hd, const ChainOps &ops, void *engine, unifor
       for (int i = 0; i < n_all; i++)
         if (rank_of[static_cast<size_t>(i)] != hd->comm_rank)  // own attempts are in the tables already
           eps_adapt_append(hd->eps, all[static_cast<size_t>(i)].accepted != 0, all[static_cast<size_t>(i)].epsilon);
+  };
+  ULONG it = 0;
+  try {
+    while (it < itmax) {  // HMC.cc:431
+      const ULONG attempt = count_attempts ? *count_attempts : it;
+      if (momenta) {  // HMC.cc:445-449 with the caller's generator
+        real_prec *p = reinterpret_cast<real_prec *>(&host_p[0]);
+        momenta(momenta_state, p, n->N);
+        chk(ops.set_momenta(engine, p), "draw_momenta");
+      } else {
+        chk(ops.draw_momenta(engine, seed, attempt), "draw_momenta");
+      }
+      update_eps_fac(hd);  // HMC.cc:453
+      // HMC.cc:260-264
+      n->Neps = static_cast<ULONG>(n->N_eps_fac * uniform(rng_state)) + 1;
+      n->epsilon = static_cast<real_prec>(n->eps_fac * uniform(rng_state));
+      if (n->epsilon > 2.) n->epsilon = 2.;
+      double dH = 0., t[6] = {0., 0., 0., 0., 0., 0.};
+      uint64_t done = 0;
+      chk(ops.attempt(engine, n->epsilon, n->Neps, &dH, t, &done), "Hamiltonian_EoM");
+      if (count_attempts) ++*count_attempts;  // HMC.cc:368
+      n->H_kin_i = t[0]; n->psi_prior_i = t[1]; n->psi_likeli_i = t[2];
+      n->H_kin_f = t[3]; n->psi_prior_f = t[4]; n->psi_likeli_f = t[5];
+      n->psi_prior = t[4]; n->psi_likeli = t[5];
+      n->dprior = t[4] - t[1];
+      n->dlikeli = t[5] - t[2];
+      n->dK = t[3] - t[0];
+      n->dE = n->dprior + n->dlikeli;
+      n->dH = dH;
+      // HMC.cc:462-486
+      real_prec p_acceptance = 1.;
+      if (dH < 0.)
+        p_acceptance = 1.;
+      else if (std::exp(-dH) < 1.)
+        p_acceptance = std::exp(-dH);
+      bool accepted;
+      if (p_acceptance >= 1.)
+        accepted = true;
+      else
+        accepted = uniform(rng_state) < p_acceptance;
+      chk(ops.accept(engine, accepted ? 1 : 0), "chain_accept");  // HMC.cc:497-498
+      if (!accepted) n->rejections++;                              // HMC.cc:500-501
+      n->accepted = accepted;                                      // HMC.cc:503-504
+      if (log && it < log_cap) {                                   // write_to_performance_log's row, HMC.cc:506
+        AttemptLog &r = log[it];
+        r.accepted = accepted;
+        r.epsilon = n->epsilon;
+        r.Neps = n->Neps;
+        r.steps_done = static_cast<ULONG>(done);
+        r.dH = dH; r.dK = n->dK; r.dE = n->dE; r.dprior = n->dprior; r.dlikeli = n->dlikeli;
+        r.psi_prior_i = t[1]; r.psi_prior_f = t[4]; r.psi_likeli_i = t[2]; r.psi_likeli_f = t[5];
+        r.H_kin_i = t[0]; r.H_kin_f = t[3];
+      }
+      update_epsilon_acc_rate_tables(hd);  // HMC.cc:507
+      if (hd->comm) {
+        bchmc_eps_record rec;
+        rec.epsilon = n->epsilon;
+        rec.accepted = accepted ? 1 : 0;
+        rec.neps = static_cast<int32_t>(n->Neps);
+        mine.push_back(rec);
+      }
+      ++it;
+      if (accepted) break;
+    }
+  } catch (...) {
+    try {
+      exchange();
+    } catch (const std::runtime_error &) {  // the first error is the one to report
+    }
+    throw;
   }
+  exchange();
   return it;
+}
+
+namespace {
+// ---- file bootstrap of the ncclUniqueId ----------------------------------------------------------------------------
+// A fixed path may hold the files of an earlier run (a reader that accepts any 128-byte file picks up last
+// run's id and blocks in ncclCommInitRank on a dead address).  So nothing is accepted on its mere existence: every
+// file carries the 64-bit nonce of the process that wrote it, and the id file echoes the nonces of the ranks it is
+// meant for.
+//   rank r > 0: writes <path>.want.<r> = { magic, nonce_r }, polls <path> until it holds { magic, world, nonce_0,
+//               id, nonce[1..world-1] } with nonce[r] == nonce_r, then writes <path>.ack.<r> = { magic, nonce_r, nonce_0 };
+//   rank 0:     removes a stale <path>, polls the want files, writes <path> (tmp + rename) with the nonces it read,
+//               and keeps polling: a want file that CHANGES (a stale one replaced by the live rank's) makes it rewrite
+//               <path>; it is done when every ack echoes (nonce_r, nonce_0) of the current <path>.
+// Every rank removes its own files when the communicator exists (bootstrap_cleanup); files of a crashed run are
+// harmless because their nonces match nothing.
+const std::uint64_t kBootMagic = 0x62636d63626f6f74ull;  // "bcmcboot"
+
+std::uint64_t boot_nonce() {
+  std::random_device rd;
+  std::uint64_t v = (static_cast<std::uint64_t>(rd()) << 32) ^ rd();
+  v ^= static_cast<std::uint64_t>(::getpid()) * 0x9E3779B97F4A7C15ull;
+  v ^= static_cast<std::uint64_t>(std::chrono::system_clock::now().time_since_epoch().count());
+  return v ? v : 1;
+}
+
+bool read_words(const std::string &path, std::vector<std::uint64_t> &w, size_t n_words) {
+  FILE *f = std::fopen(path.c_str(), "rb");
+  if (!f) return false;
+  w.assign(n_words, 0);
+  const size_t got = std::fread(w.data(), sizeof(std::uint64_t), n_words, f);
+  const bool more = std::fgetc(f) != EOF;
+  std::fclose(f);
+  return got == n_words && !more && w[0] == kBootMagic;
+}
+
+void write_words(const std::string &path, const std::vector<std::uint64_t> &w) {
+  const std::string tmp = path + ".tmp." + std::to_string(::getpid());
+  FILE *f = std::fopen(tmp.c_str(), "wb");
+  if (!f || std::fwrite(w.data(), sizeof(std::uint64_t), w.size(), f) != w.size() || std::fclose(f) != 0)
+    throw std::runtime_error("In comm_bootstrap_file: cannot write " + tmp);
+  if (std::rename(tmp.c_str(), path.c_str()) != 0)  // atomic: readers never see a partial file
+    throw std::runtime_error("In comm_bootstrap_file: cannot rename to " + path);
+}
+}  // namespace
+
+void bootstrap_exchange_id(const char *path_c, int rank, int world, double timeout_s,
+                           unsigned char id[BCHMC_UNIQUE_ID_BYTES]) {
+  if (!path_c || !id || world < 1 || rank < 0 || rank >= world)
+    throw std::runtime_error("In comm_bootstrap_file: bad argument");
+  const std::string path(path_c);
+  constexpr size_t kIdWords = BCHMC_UNIQUE_ID_BYTES / sizeof(std::uint64_t);
+  const size_t id_file_words = 3 + kIdWords + static_cast<size_t>(world);  // magic, world, nonce_0, id, nonce[world]
+  const auto t0 = std::chrono::steady_clock::now();
+  auto expired = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s; };
+  auto nap = [] { std::this_thread::sleep_for(std::chrono::milliseconds(10)); };
+  auto want = [&](int r) { return path + ".want." + std::to_string(r); };
+  auto ack = [&](int r) { return path + ".ack." + std::to_string(r); };
+  const std::uint64_t mine = boot_nonce();
+  std::vector<std::uint64_t> w;
+  if (rank == 0) {
+    std::remove(path.c_str());  // whatever an earlier run left here is not ours
+    std::vector<std::uint64_t> seen(static_cast<size_t>(world), 0), written;
+    for (;;) {
+      bool all_want = true, changed = false;
+      for (int r = 1; r < world; r++) {
+        if (read_words(want(r), w, 2) && w[1] != 0) {
+          if (w[1] != seen[static_cast<size_t>(r)]) {
+            seen[static_cast<size_t>(r)] = w[1];
+            changed = true;
+          }
+        } else if (seen[static_cast<size_t>(r)] == 0) {
+          all_want = false;
+        }
+      }
+      if (all_want && (changed || written.empty())) {
+        written.assign(id_file_words, 0);
+        written[0] = kBootMagic;
+        written[1] = static_cast<std::uint64_t>(world);
+        written[2] = mine;
+        std::memcpy(&written[3], id, BCHMC_UNIQUE_ID_BYTES);
+        for (int r = 1; r < world; r++) written[3 + kIdWords + static_cast<size_t>(r)] = seen[static_cast<size_t>(r)];
+        write_words(path, written);
+      }
+      if (!written.empty()) {
+        bool all_ack = true;
+        for (int r = 1; r < world && all_ack; r++)
+          all_ack = read_words(ack(r), w, 3) && w[1] == seen[static_cast<size_t>(r)] && w[2] == mine;
+        if (all_ack) return;
+      }
+      if (expired()) throw std::runtime_error("In comm_bootstrap_file: timed out waiting for the other ranks at " + path);
+      nap();
+    }
+  }
+  std::remove(ack(rank).c_str());
+  write_words(want(rank), {kBootMagic, mine});
+  for (;;) {
+    if (read_words(path, w, id_file_words) && w[1] == static_cast<std::uint64_t>(world) &&
+        w[3 + kIdWords + static_cast<size_t>(rank)] == mine) {
+      std::memcpy(id, &w[3], BCHMC_UNIQUE_ID_BYTES);
+      write_words(ack(rank), {kBootMagic, mine, w[2]});
+      return;
+    }
+    if (expired()) throw std::runtime_error("In comm_bootstrap_file: timed out waiting for " + path);
+    nap();
+  }
+}
+
+void bootstrap_cleanup(const char *path_c, int rank) {
+  if (!path_c) return;
+  const std::string path(path_c);
+  if (rank == 0) {
+    std::remove(path.c_str());
+  } else {
+    std::remove((path + ".want." + std::to_string(rank)).c_str());
+    std::remove((path + ".ack." + std::to_string(rank)).c_str());
+  }
 }
 
 void comm_bootstrap_file(HamilView *hd, const char *path, int rank, int world, double timeout_s) {
   if (!hd || !path) throw std::runtime_error("In comm_bootstrap_file: bad argument");
   unsigned char id[BCHMC_UNIQUE_ID_BYTES];
-  const std::string final_path(path), tmp_path = final_path + ".tmp";
+  std::memset(id, 0, sizeof id);
   if (rank == 0) {
     const int rc = bchmc_comm_unique_id(id);
     if (rc) throw std::runtime_error(std::string("In bchmc_comm_unique_id: ") + bchmc_strerror(rc));
-    FILE *f = std::fopen(tmp_path.c_str(), "wb");
-    if (!f || std::fwrite(id, 1, sizeof id, f) != sizeof id || std::fclose(f) != 0)
-      throw std::runtime_error("In comm_bootstrap_file: cannot write " + tmp_path);
-    if (std::rename(tmp_path.c_str(), final_path.c_str()) != 0)  // atomic: readers never see a partial id
-      throw std::runtime_error("In comm_bootstrap_file: cannot rename to " + final_path);
-  } else {
-    const auto t0 = std::chrono::steady_clock::now();
-    for (;;) {
-      FILE *f = std::fopen(final_path.c_str(), "rb");
-      if (f) {
-        const size_t got = std::fread(id, 1, sizeof id, f);
-        std::fclose(f);
-        if (got == sizeof id) break;
-      }
-      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s)
-        throw std::runtime_error("In comm_bootstrap_file: timed out waiting for " + final_path);
-      std::this_thread::sleep_for(std::chrono::milliseconds(20));
-    }
   }
+  bootstrap_exchange_id(path, rank, world, timeout_s, id);
   bchmc_comm *c = nullptr;
-  const int rc = bchmc_comm_create(id, rank, world, hd->device, &c);
+  const int rc = bchmc_comm_create(id, rank, world, hd->device, &c);  // ncclCommInitRank: returns once every rank joined
+  bootstrap_cleanup(path, rank);  // every rank has read what it needed (rank 0 saw all acks before it got here)
   if (rc) {
     std::string msg = std::string("In bchmc_comm_create: ") + bchmc_strerror(rc);
     if (c && bchmc_comm_last_error(c)[0]) msg += std::string(" (") + bchmc_comm_last_error(c) + ")";
@@ -348,11 +527,15 @@ void comm_release(HamilView *hd) {
 }
 
 void inputs_changed(HamilView *hd) {
-  if (hd) hd->inputs_generation++;  // the next engine_for() uploads the arrays again (once, not per call)
+  if (!hd) return;
+  hd->inputs_generation++;  // the next engine_for() uploads the arrays again (once, not per call)
+  hd->eom.valid = false;
 }
 
 void mass_changed(HamilView *hd) {
-  if (hd) hd->mass_generation++;
+  if (!hd) return;
+  hd->mass_generation++;
+  hd->eom.valid = false;
 }
 
 void release(HamilView *hd) {
@@ -489,6 +672,11 @@ int bchmc_shim_comm_bootstrap_file(bchmc_shim::HamilView *hd, const char *path, 
                                    char *err, size_t errlen) {
   return guarded(err, errlen, [&] { bchmc_shim::comm_bootstrap_file(hd, path, rank, world, timeout_s); });
 }
+int bchmc_shim_bootstrap_exchange_id(const char *path, int rank, int world, double timeout_s, unsigned char *id, char *err,
+                                     size_t errlen) {
+  return guarded(err, errlen, [&] { bchmc_shim::bootstrap_exchange_id(path, rank, world, timeout_s, id); });
+}
+void bchmc_shim_bootstrap_cleanup(const char *path, int rank) { bchmc_shim::bootstrap_cleanup(path, rank); }
 int bchmc_shim_comm_attach(bchmc_shim::HamilView *hd, bchmc_comm *comm, int rank) {
   if (!hd) return 1;
   hd->comm = comm;

@@ -39,6 +39,14 @@ def parse():
     ap.add_argument("--no-rsd", action="store_true")
     ap.add_argument("--alpt", action="store_true",
                     help="with --no-rsd: sfmodel = 2, the ALPT forward model (Lag2Eul_non_zeldovich) in every force evaluation")
+    ap.add_argument("--mk", type=int, default=3, help="masskernel 0 NGP / 1 CIC / 2 TSC / 3 SPH (default; anything else is a "
+                                                      "separate line, never the headline)")
+    ap.add_argument("--calc-h", type=int, default=2, help="likelihood-force variant 0..3 (default 2; mk != 3 needs 0 or 1)")
+    ap.add_argument("--sustained", type=float, default=0.0,
+                    help="additionally run ONE trajectory long enough for about this many seconds (>= 3 to be called "
+                         "sustained) and report it as `sustained` next to the headline")
+    ap.add_argument("--no-rccl-probe", action="store_true",
+                    help="N > 1 on nccl: skip the untimed ncclAllGather through the library's own RCCL transport")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-nx", type=int, default=0, help="grid of the CPU-baseline sample (default: same as --nx)")
     ap.add_argument("--no-kernel-profile", action="store_true")
@@ -55,13 +63,21 @@ def parse():
     return ap.parse_args()
 
 
+def _profile_key(path):
+    """Sort key of a profiles/ file name: (round, version) as NUMBERS -- r02_v9 < r02_v17 < r03_v1 -- then the name."""
+    import re
+    name = os.path.basename(path)
+    m = re.match(r"r(\d+)(?:_v(\d+))?", name)
+    return (int(m.group(1)) if m else -1, int(m.group(2)) if (m and m.group(2)) else 0, name)
+
+
 def pmc_traffic(nx, precision):
     """HBM bytes per leapfrog step from the newest committed rocprofv3 PMC summary (profiles/r*_pmc_traffic.json,
     made by scripts/pmc_traffic.py from separate FETCH_SIZE / WRITE_SIZE passes of this bench command).
     Returns None when no summary exists for this grid."""
     import glob
     best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json"))):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")), key=_profile_key):
         try:
             d = json.load(open(path))
         except (OSError, ValueError):
@@ -138,7 +154,7 @@ def valu_roofline():
     (profiles/r*_sq_tile81.json, made by scripts/pmc_sq.py from separate rocprofv3 --pmc passes of this bench
     command; PMC needs its own passes, so this is never measured inside the timed run)."""
     import glob
-    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sq_tile81.json")))
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sq_tile81.json")), key=_profile_key)
     if not paths:
         return None
     try:
@@ -184,12 +200,66 @@ def two_chain_throughput(params, fields, arrays, dev, local_rank, eps, steps, pr
                 note="opt-in deployment mode for many-chain sampling; the headline `value` is one chain on the whole GPU")
 
 
+def rccl_native_probe(group, dist, dev, rank, world, eps, steps, timeout_s=90.0):
+    """Untimed: the same exchange once more through the LIBRARY's own RCCL transport (bchmc_comm_create: ncclCommInitRank
+    + ncclAllGather behind the C ABI, what a barcode/main.cc-driven chain uses), whatever transport the timed exchange
+    ran on.  Runs in a thread with a deadline, so a transport that cannot come up is reported, not waited for."""
+    import threading
+    from barcode_amd import engine as _eng
+    res = dict(ok=False)
+
+    def work():
+        try:
+            uid = [_eng.Comm.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            c = _eng.Comm(rank, world, device=dev.index, unique_id=uid[0])
+            got = c.exchange([(eps, True, steps)])
+            info = c.info()
+            res.update(transport=info["transport"], world_seen=info["world"],
+                       ranks_seen=sorted({int(r[0]) for r in got}), records=len(got))
+            res["ok"] = bool(info["transport"] == "rccl" and info["world"] == world and
+                             res["ranks_seen"] == list(range(world)) and len(got) == world)
+            c.close()
+        except Exception as e:  # reported in the line, never fatal for the measurement
+            res["error"] = "%s: %s" % (type(e).__name__, e)
+
+    t = threading.Thread(target=work, daemon=True)
+    t.start()
+    t.join(timeout_s)
+    if t.is_alive():
+        res["error"] = "no answer within %.0f s" % timeout_s
+        res["hung"] = True
+    return res
+
+
+def sustained_run(engine, q0, p0, q1, p1, eps, ms_per_step, seconds, torch):
+    """ONE trajectory of about `seconds` seconds (steps from the headline's ms per step), timed on the engine's stream,
+    with a split per fifth of the trajectory taken from HIP events recorded by a second, shorter pass."""
+    steps = max(int(seconds * 1e3 / ms_per_step), 10)
+    t0 = time.perf_counter()
+    engine.leapfrog_device(q0, p0, q1, p1, eps, steps)
+    done = engine.steps_done()
+    dt = time.perf_counter() - t0
+    # per-segment rates: five consecutive trajectories of steps / 5 (each carries the ~1.1-step fixed cost)
+    seg, rates = max(steps // 5, 1), []
+    for _ in range(5):
+        s0 = time.perf_counter()
+        engine.leapfrog_device(q0, p0, q1, p1, eps, seg)
+        engine.steps_done()
+        rates.append(round(seg / (time.perf_counter() - s0), 2))
+    return dict(value=round(steps / dt, 4), unit="steps/s", steps=steps, seconds=round(dt, 3), steps_done=int(done),
+                ms_per_step=round(1e3 * dt / steps, 4), fifths_steps_per_s=rates,
+                note="one trajectory, inputs resident, wall clock around launch + synchronise")
+
+
 def launch_ranks(args):
     """Parent of a self-launched multi-GPU run: start one child per GPU, never touch the GPU here."""
     import socket
     import subprocess
     import torch
     ndev = torch.cuda.device_count()  # counting devices does not initialise the GPU runtime in this process
+    # the children are fresh processes (never a re-exec of this one), and this one must stay off the GPU for good
+    assert not torch.cuda.is_initialized(), "bench.py parent initialised the GPU before spawning its ranks"
     if args.gpus > ndev and not args.single_device:
         print("bench.py: --gpus %d but this node shows %d GPU(s): refusing to run" % (args.gpus, ndev), file=sys.stderr)
         sys.exit(2)
@@ -218,6 +288,7 @@ def launch_ranks(args):
                     rcs[i] = pr.wait()
             break
         time.sleep(0.1)
+    assert not torch.cuda.is_initialized()
     out0 = procs[0].stdout.read()  # one JSON line: far below the pipe buffer, safe to read after the exit
     # exactly one JSON line on stdout: libraries of the children may have written their own chatter there
     for line in out0.decode().splitlines():
@@ -273,7 +344,9 @@ def main():
     rsd = 0 if args.no_rsd else 1
     # BASELINE config 3: "256^3, 2LPT + RSD": under rsd_model the reference dispatches to Zel'dovich + plane-parallel
     # RSD whatever sfmodel says; Gaussian likelihood, SPH kernel, calc_h 2, mass_type 1, fp64.
-    params = HamilParams(Nx=args.nx, L=200.0, likelihood=args.likelihood, rsd_model=rsd, sfmodel=2 if (rsd or args.alpt) else 1)
+    params = HamilParams(Nx=args.nx, L=200.0, likelihood=args.likelihood, rsd_model=rsd, sfmodel=2 if (rsd or args.alpt) else 1,
+                         mk=args.mk, calc_h=args.calc_h)
+    headline_variant = (args.mk == 3 and args.calc_h == 2)
     group = ChainGroup(pool=True, device=dev if args.backend == "nccl" else torch.device("cpu"),
                        transport=args.exchange)
     ring = EpsRing()
@@ -307,7 +380,7 @@ def main():
     if args.warmup > 0:
         engine.leapfrog_device(q0, p0, q1, p1, eps, args.warmup)
         engine.sync()
-    group.pool_into(ring, [(eps, True, args.warmup)])  # untimed: first use of the collective sets up RCCL's channels
+    got_w = group.pool_into(ring, [(eps, True, args.warmup)])  # untimed: first use of the collective sets up RCCL's channels
     stream = torch.cuda.ExternalStream(engine.stream, device=dev)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
@@ -320,7 +393,7 @@ def main():
     ev1.record(stream)
     done = engine.steps_done()  # synchronises the engine's stream
     ring.record(True, eps)
-    group.pool_into(ring, [(eps, True, args.steps)])  # the path's only collective: one 520-byte packet per rank per sample
+    got_t = group.pool_into(ring, [(eps, True, args.steps)])  # the path's only collective: one 520-byte packet per rank per sample
     torch.cuda.synchronize()
     barrier()
     t1 = time.perf_counter()
@@ -330,6 +403,28 @@ def main():
         t = torch.tensor([wall], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
+    # what the collective itself saw (so that a recorded N-GPU line needs no inference about the rank count): the
+    # communicator's own world size, the set of ranks whose records arrived in the timed exchange, the record count
+    collective = dict(backend=(args.backend if distributed else None),
+                      transport=(group.comm.info()["transport"] if group.comm is not None else "none"),
+                      exchange=args.exchange if distributed else None,
+                      world_seen=(group.comm.info()["world"] if group.comm is not None else 1),
+                      ranks_seen=sorted({int(r[0]) for r in got_t}), records=len(got_t),
+                      warmup_records=len(got_w), in_timed_region=True)
+    if distributed:
+        # every rank must have seen the same thing
+        seen = torch.tensor([collective["world_seen"], len(collective["ranks_seen"]), collective["records"]],
+                            dtype=torch.int64, device=dev if args.backend == "nccl" else "cpu")
+        lo, hi = seen.clone(), seen.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        collective["consistent_across_ranks"] = bool(torch.equal(lo, hi))
+        collective["ok"] = bool(collective["consistent_across_ranks"] and collective["world_seen"] == world and
+                                collective["ranks_seen"] == list(range(world)) and collective["records"] == world)
+    else:
+        collective["ok"] = collective["ranks_seen"] == [0] and collective["records"] == 1
+    if distributed and args.backend == "nccl" and not args.single_device and not args.no_rccl_probe:
+        collective["rccl_native"] = rccl_native_probe(group, dist, dev, rank, world, eps, args.steps)
     if done != args.steps:
         print("bench.py: runaway guard fired after %d of %d steps" % (done, args.steps), file=sys.stderr)
     finite = bool(torch.isfinite(q1).all().item() and torch.isfinite(p1).all().item())
@@ -352,6 +447,9 @@ def main():
                         bound="fp64 vector ALU + LDS atomics (DESIGN.md section 5), not HBM"
                         if dom in ("k_scatter_sph", "k_gather_sph") else "hbm")
 
+    sustained = None
+    if args.sustained > 0 and world == 1:
+        sustained = sustained_run(engine, q0, p0, q1, p1, eps, 1e3 * wall / args.steps, args.sustained, torch)
     throughput_mode = None
     if args.chains_per_gpu == 2 and world == 1:
         throughput_mode = two_chain_throughput(params, f, arrays, dev, local_rank, eps, args.steps, 1 if args.fp32 else 0)
@@ -363,9 +461,10 @@ def main():
         algo = ALGO_BYTES_PER_CELL_STEP // (2 if args.fp32 else 1)  # 272 N bytes per step with fp32 fields
         achieved = algo * N * args.steps / (gpu_ms * 1e-3) / 1e9  # per GPU, device time
         traffic, traffic_src = (pmc_traffic(params.Nx, "fp32" if args.fp32 else "fp64")
-                                if (rsd and params.likelihood == 1) else (None, None))
+                                if (rsd and params.likelihood == 1 and headline_variant) else (None, None))
         out = {
-            "metric": "HMC leapfrog steps/sec on %d^3 grid" % params.Nx,
+            "metric": "HMC leapfrog steps/sec on %d^3 grid" % params.Nx + ("" if headline_variant else
+                                                                        " (variant mk=%d calc_h=%d: not the headline)" % (args.mk, args.calc_h)),
             "value": round(value, 4),
             "unit": "steps/s",
             "n_gpus": world,
@@ -378,19 +477,20 @@ def main():
             "dtype": "f32" if args.fp32 else "f64",
             "data": "synthetic",
             "config": {
-                "workload": "%d^3 grid, L=200 Mpc/h, Gaussian prior, %s, likelihood=%d, SPH mass kernel (mk=3), calc_h=2, mass_type=1, %s; one "
+                "workload": "%d^3 grid, L=200 Mpc/h, Gaussian prior, %s, likelihood=%d, mass kernel mk=%d (3 = SPH), calc_h=%d, mass_type=1, %s; one "
                             "trajectory of %d leapfrog steps per chain" % (params.Nx,
                                                                            ("Zel'dovich + plane-parallel RSD (reference "
                                                                             "behaviour of '2LPT+RSD', SURVEY M3)") if rsd else
                                                                            ("ALPT forward model (sfmodel=2, kth=4)"
                                                                             if args.alpt else "Zel'dovich"),
-                                                                           params.likelihood,
+                                                                           params.likelihood, args.mk, args.calc_h,
                                                                            "fp32 field arrays" if args.fp32 else "fp64",
                                                                            args.steps),
                 "grid": params.Nx, "chains": world, "parallelism": "independent chains, 1 per GPU",
                 "rehearsal_single_device": bool(args.single_device),
                 "eps": eps, "steps_done": int(done), "finite": finite,
             },
+            "collective": collective,
             "roofline": {
                 "bound": "hbm",
                 "kernel": "whole leapfrog step (all kernels + 6 rocFFT transforms)",
@@ -406,11 +506,14 @@ def main():
                 "dominant_kernel": dominant,
                 "kernels": kernels,
                 # the two particle-mesh kernels are fp64-VALU bound, not HBM bound: reported against 78.6 TFLOP/s
-                "valu": valu_roofline() if (rsd and params.likelihood == 1 and not args.fp32 and params.Nx == 256) else None,
+                "valu": valu_roofline() if (rsd and params.likelihood == 1 and not args.fp32 and params.Nx == 256 and
+                                            headline_variant) else None,
             },
         }
         if throughput_mode is not None:
             out["throughput_mode"] = throughput_mode
+        if sustained is not None:
+            out["sustained"] = sustained
         if world == 1 and not args.no_cpu_baseline:
             cpu_params = params
             cq0, cp0, carr = f["q0"], p0_host, arrays

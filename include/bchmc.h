@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define BCHMC_ABI_VERSION 3
+#define BCHMC_ABI_VERSION 4
 
 /* Scalars of HAMIL_NUMERICAL / HAMIL_DATA read by the path (barlib/include/struct_hamil.h:51-222);
  * filled by the shim from the HAMIL_DATA that call_hamil.cc:42 builds.  Cubic grids only, like the
@@ -54,7 +54,10 @@ typedef struct bchmc_config {
                               * (integer adds are order-independent), the density is converted and summed in a fixed
                               * order; one extra pass over the grid per force evaluation.  0: hardware float atomics,
                               * last bits vary from run to run like the reference's OpenMP build (barcode/main.cc:86-90).
-                              * BCHMC_DETERMINISTIC=1 in the environment switches it on for every handle. */
+                              * BCHMC_DETERMINISTIC=1 in the environment switches it on for every handle.
+                              * Range: contributions are scaled to 2^46 per maximal one (W(0), or weight 1), so a cell
+                              * holds 2^17 of them before the 63-bit sum wraps; a cell that passed 2^16 (or came out
+                              * negative) makes the next synchronising call return BCHMC_ERR_STATE. */
   int32_t reserved0;
 } bchmc_config;
 
@@ -117,6 +120,19 @@ int bchmc_fetch(bchmc_handle *h, bchmc_field field, double *host, size_t n);
 int bchmc_leapfrog(bchmc_handle *h, const double *q0, const double *p0, double *q1, double *p1, double eps,
                    uint64_t neps, uint64_t *steps_done);
 
+/* Hamiltonian_EoM (HMC.cc:251-369) and delta_Hamiltonian (HMC.cc:209-248) of the same four arrays in ONE pass --
+ * what HamiltonianMC does with consecutive calls at HMC.cc:455 and 459.  Same (q1, p1, *steps_done) as bchmc_leapfrog;
+ * *dH and terms as bchmc_delta_hamiltonian would return for (q0, p0, q1, p1): K and psi_prior of both ends are
+ * Parseval sums of the k-space state, -log L of both ends comes from the trajectory's own first and last force
+ * evaluation where log_like's forward model is the force's one (else, and for real-space masses and the GRF
+ * likelihood, the energies are evaluated around the trajectory) -- four array uploads and two forward models fewer
+ * than the two separate calls.  The reuse is the CALLER's statement, made by choosing this entry point: the engine
+ * keeps no memory of earlier calls, and bchmc_delta_hamiltonian always evaluates what it is given.  Leaves
+ * psi(q1)'s deltaX / pos* in the handle (HMC.cc:225).  (ABI version 4; replaces the pointer + sampled-content
+ * cache version 3 kept inside bchmc_delta_hamiltonian.) */
+int bchmc_leapfrog_dh(bchmc_handle *h, const double *q0, const double *p0, double *q1, double *p1, double eps,
+                      uint64_t neps, uint64_t *steps_done, double *dH, double terms[6]);
+
 /* kinetic_term + psi (HMC.cc:64-143): out = { H_kin, psi_prior, psi_likeli } at (q, p).  Leaves
  * deltaX / pos* of this evaluation in the handle like the reference's log_like does. */
 int bchmc_energies(bchmc_handle *h, const double *q, const double *p, double out[3]);
@@ -128,7 +144,8 @@ int bchmc_kinetic_term(bchmc_handle *h, const double *p, double *out);
 int bchmc_psi(bchmc_handle *h, const double *q, double psi_out[2]);
 
 /* delta_Hamiltonian (HMC.cc:209-248): terms = { H_kin_i, psi_prior_i, psi_likeli_i, H_kin_f,
- * psi_prior_f, psi_likeli_f }, *dH includes div_dH_by_N. */
+ * psi_prior_f, psi_likeli_f }, *dH includes div_dH_by_N.  Always a full evaluation of the arrays passed in, against
+ * the inputs uploaded at the time of the call (no result of an earlier call is reused). */
 int bchmc_delta_hamiltonian(bchmc_handle *h, const double *qi, const double *pi, const double *qf, const double *pf,
                             double *dH, double terms[6]);
 
@@ -225,11 +242,16 @@ const char *bchmc_comm_last_error(const bchmc_comm *c);
 /* One exchange (ncclAllGather of 520 bytes per rank on the side stream): queue `n_mine` (>= 0) records of this rank,
  * send the oldest <= BCHMC_EPS_BATCH queued ones, and return every rank's contribution in rank order, the own one
  * included: all[0 .. *n_all - 1], rank_of[i] = contributing rank of all[i] (rank_of may be NULL).  `cap` = capacity of
- * `all` (world * BCHMC_EPS_BATCH always suffices).  Every rank of the communicator must call it the same number of
- * times. */
+ * `all`, at least world * BCHMC_EPS_BATCH (checked before anything is sent).  Every rank of the communicator must call
+ * it the same number of times.  Failure semantics: a call that returns non-zero has queued nothing of `mine` on this
+ * rank -- retry with the same records, or drop them; after a TRANSPORT failure (the collective itself broke) the
+ * communicator is no longer usable: the peers may or may not have completed the all-gather. */
 int bchmc_eps_exchange(bchmc_comm *c, const bchmc_eps_record *mine, int n_mine, bchmc_eps_record *all, int *rank_of,
                        int cap, int *n_all);
 int bchmc_comm_pending(const bchmc_comm *c); /* own records still queued for a later exchange */
+int bchmc_comm_world(const bchmc_comm *c);   /* ranks of the communicator (sizes the caller's `all` / `rank_of`) */
+int bchmc_comm_rank(const bchmc_comm *c);
+const char *bchmc_comm_transport(const bchmc_comm *c); /* "rccl", "custom" or "none" (one rank, nothing to move) */
 
 #ifdef __cplusplus
 }

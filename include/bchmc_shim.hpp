@@ -76,6 +76,22 @@ struct HamilView {
   // the same for mass_f / mass_r alone (mass_changed()): what HamiltonianMC rewrites every sample.  Unlike the other
   // inputs the mass does not enter gradient_psi or -log L, so the resident chain keeps its carried gradient.
   unsigned long mass_generation = 0, mass_uploaded_generation = 0;
+  // Hamiltonian_EoM runs bchmc_leapfrog_dh, which yields the six energy terms of its four arrays with the trajectory;
+  // delta_Hamiltonian may answer from them when it is the NEXT call on this view, about the same four arrays, with no
+  // inputs_changed() / mass_changed() in between -- HamiltonianMC's order, HMC.cc:455-459.  The C ABI itself never
+  // reuses anything.  reuse_eom_energies: 0 = delta_Hamiltonian always evaluates; 1 = reuse on array identity (the
+  // caller's contract: the four arrays are not written between the two calls); 2 = identity and a 64-bit hash of the
+  // full contents of all four arrays, taken in Hamiltonian_EoM and checked in delta_Hamiltonian (reads 4 N doubles
+  // twice on the host: for callers that cannot make that promise).
+  int reuse_eom_energies = 1;
+  struct EomEnergies {
+    bool valid = false;
+    const real_prec *ptr[4] = {nullptr, nullptr, nullptr, nullptr};  // signali, momentai, signalf, momentaf
+    std::uint64_t hash[4] = {0, 0, 0, 0};                            // mode 2 only
+    double terms[6] = {0, 0, 0, 0, 0, 0};
+    double dH = 0;
+    unsigned long inputs_generation = 0, mass_generation = 0;
+  } eom;
 };
 
 // Stand-in for gsl_rng_uniform(seed): called exactly where the reference calls it, in its order.
@@ -161,9 +177,15 @@ ULONG HamiltonianMC_ops(HamilView *hd, const ChainOps &ops, void *engine, unifor
                         momenta_fn momenta, void *momenta_state);
 
 // Rank bootstrap for the RCCL transport when no launcher hands the unique id around (barcode/main.cc is a plain
-// process per GPU): rank 0 writes the 128 bytes to `path` (write to path.tmp, then rename), the others poll for it
-// (timeout_s seconds).  Sets hd->comm.
+// process per GPU): the 128 bytes travel through files next to `path` (<path>, <path>.want.<r>, <path>.ack.<r>).
+// Every file carries the nonce of the process that wrote it and the id file echoes the nonces of the ranks it is for,
+// so files left behind by an earlier run at the same path are never taken for this run's (hmc_hip_shim.cc); each rank
+// removes its own files once the communicator exists.  Ranks of ONE run share `path`; two runs at the same time need
+// different paths.  Sets hd->comm; throws after timeout_s seconds.
 void comm_bootstrap_file(HamilView *hd, const char *path, int rank, int world, double timeout_s);
+// the file protocol on its own (host only): rank 0 passes the id in, the other ranks receive it
+void bootstrap_exchange_id(const char *path, int rank, int world, double timeout_s, unsigned char id[BCHMC_UNIQUE_ID_BYTES]);
+void bootstrap_cleanup(const char *path, int rank);
 void comm_release(HamilView *hd);
 
 // hd's input arrays changed (HamiltonianMC recomputes the mass every sample, HMC.cc:400-423): upload them again
@@ -207,6 +229,9 @@ int bchmc_shim_update_eps_fac(bchmc_shim::HamilView *hd, char *msg, size_t msgle
 int bchmc_shim_update_tables(bchmc_shim::HamilView *hd, char *err, size_t errlen);
 int bchmc_shim_comm_bootstrap_file(bchmc_shim::HamilView *hd, const char *path, int rank, int world, double timeout_s,
                                    char *err, size_t errlen);
+int bchmc_shim_bootstrap_exchange_id(const char *path, int rank, int world, double timeout_s, unsigned char *id, char *err,
+                                     size_t errlen);
+void bchmc_shim_bootstrap_cleanup(const char *path, int rank);
 int bchmc_shim_comm_attach(bchmc_shim::HamilView *hd, bchmc_comm *comm, int rank); /* tests: a custom-transport communicator */
 void bchmc_shim_comm_release(bchmc_shim::HamilView *hd);
 void bchmc_shim_inputs_changed(bchmc_shim::HamilView *hd);

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Time one HamiltonianMC attempt (momenta + trajectory + delta_Hamiltonian) two ways on the GPU box:
-  host-array path:  bchmc_leapfrog + bchmc_delta_hamiltonian with numpy arrays (what the thin reference shim binds),
+  host-array path:  bchmc_leapfrog_dh with numpy arrays (what the reference shim binds: Hamiltonian_EoM keeps the six
+                    terms for the delta_Hamiltonian that follows), and bchmc_leapfrog + bchmc_delta_hamiltonian (the
+                    latter always evaluates) for comparison,
   resident chain:   bchmc_chain_draw_momenta + bchmc_chain_attempt + bchmc_chain_accept.
 Usage: python scripts/attempt_bench.py [nx] [neps]"""
 import json
@@ -28,7 +30,9 @@ q0, p0 = f["q0"].ravel().copy(), f["p0"].ravel().copy()
 q1, p1 = np.zeros(p.N), np.zeros(p.N)   # signalf / momentaf: allocated once per sample upstream (HMC.cc:375)
 
 
-def host_path():
+def host_path(one_pass=True):
+    if one_pass:
+        return e.leapfrog_dh(q0, p0, eps, neps, out=(q1, p1))[3]
     e.leapfrog(q0, p0, eps, neps, out=(q1, p1))
     return e.delta_hamiltonian(q0, p0, q1, p1)[0]
 
@@ -62,17 +66,16 @@ t2b = time.perf_counter()
 for i in range(reps):
     chain_path(201 + i, True)
 t2c = time.perf_counter()
-os.environ["BCHMC_NO_DH_CACHE"] = "1"   # the r01 protocol: plain trajectory, then two full energy evaluations
-host_path()
+host_path(False)                          # the r01 protocol: plain trajectory, then two full energy evaluations
 t3 = time.perf_counter()
 for _ in range(reps):
-    host_path()
+    host_path(False)
 t4 = time.perf_counter()
 print(json.dumps(dict(grid=nx, neps=neps, host_array_ms_per_attempt=1e3 * (t1 - t0) / reps,
                       resident_chain_ms_per_attempt=1e3 * (t2 - t1) / reps,
                       resident_chain_all_accepted_ms=1e3 * (t2a - t2) / reps,
                       resident_chain_gradient_recomputed_ms=1e3 * (t2c - t2b) / reps,
                       host_array_without_trajectory_reuse_ms=1e3 * (t4 - t3) / reps,
-                      note="host path = bchmc_leapfrog + bchmc_delta_hamiltonian on caller arrays (pinned staging, "
-                           "energies taken from the trajectory's own pass); excludes the host-side momentum draw the "
+                      note="host path = bchmc_leapfrog_dh on caller arrays (pinned staging, energies taken from the "
+                           "trajectory's own pass; bchmc_delta_hamiltonian itself always evaluates); excludes the host-side momentum draw the "
                            "reference does per attempt")))

@@ -78,7 +78,7 @@ def test_exchange_rejects_a_transport_that_scribbles():
     c = eng.Comm(rank=0, world=2, allgather=lambda send: send + bad_count)
     with pytest.raises(eng.BchmcError, match="malformed"):
         c.exchange([(1.0, True, 1)])
-    assert c.pending() == 1                                                # nothing was consumed
+    assert c.pending() == 0        # a failed call keeps none of its records queued: the caller retries with them
     c.close()
     c2 = eng.Comm(rank=0, world=2, allgather=lambda send: b"short")
     with pytest.raises(eng.BchmcError):
@@ -293,3 +293,101 @@ def test_eps_stats_exchange_gloo_unequal_attempts(tmp_path, world):
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
         assert "ok" in o
+
+
+# ---- file bootstrap of the RCCL unique id (bchmc_shim::bootstrap_exchange_id; host only) ---------------------------
+def _bootstrap_ranks(path, world, uid, delays, timeout_s=20.0):
+    """Run the protocol for all ranks in threads (ctypes releases the GIL in the foreign call)."""
+    import threading
+    import time
+    from barcode_amd import shim
+    out, errs = [None] * world, [None] * world
+
+    def run(r):
+        time.sleep(delays[r])
+        try:
+            out[r] = shim.bootstrap_exchange_id(path, r, world, uid if r == 0 else None, timeout_s)
+        except shim.ShimError as e:
+            errs[r] = str(e)
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    return out, errs
+
+
+def test_bootstrap_file_protocol_delivers_rank0_id(tmp_path):
+    from barcode_amd import shim
+    path = str(tmp_path / "chain.id")
+    uid = bytes(range(128))
+    out, errs = _bootstrap_ranks(path, 3, uid, [0.0, 0.05, 0.1])
+    assert errs == [None] * 3 and out == [uid] * 3
+    for r in range(3):
+        shim.bootstrap_cleanup(path, r)
+    assert os.listdir(str(tmp_path)) == []       # every rank removed its own files
+
+
+def test_bootstrap_ignores_the_files_of_an_earlier_run(tmp_path):
+    """the second run at a fixed path must not pick up the first run's id (ncclCommInitRank would block on
+    a dead address).  Stale files of every kind are in place: a raw 128-byte id (the r02 format), a well-formed id
+    file and want / ack files with the nonces of dead processes -- in both start orders."""
+    import struct
+    path = str(tmp_path / "chain.id")
+    magic = 0x62636d63626f6f74
+    old_id, new_id = bytes([7] * 128), bytes(range(100, 228))
+
+    def plant():
+        open(path, "wb").write(struct.pack("<3Q", magic, 3, 111) + old_id + struct.pack("<3Q", 0, 222, 333))
+        open(path + ".want.1", "wb").write(struct.pack("<2Q", magic, 222))
+        open(path + ".want.2", "wb").write(struct.pack("<2Q", magic, 333))
+        open(path + ".ack.1", "wb").write(struct.pack("<3Q", magic, 222, 111))
+        open(path + ".ack.2", "wb").write(struct.pack("<3Q", magic, 333, 111))
+
+    plant()
+    out, errs = _bootstrap_ranks(path, 3, new_id, [0.0, 0.3, 0.5])     # rank 0 first: it sees the stale want files
+    assert errs == [None] * 3 and out == [new_id] * 3
+    plant()
+    out, errs = _bootstrap_ranks(path, 3, new_id, [0.4, 0.0, 0.1])     # the others first: they see the stale id file
+    assert errs == [None] * 3 and out == [new_id] * 3
+    open(path, "wb").write(old_id)                                       # the r02 format: 128 raw bytes
+    out, errs = _bootstrap_ranks(path, 2, new_id, [0.3, 0.0])
+    assert errs == [None] * 2 and out == [new_id] * 2
+
+
+def test_bootstrap_times_out_instead_of_hanging(tmp_path):
+    from barcode_amd import shim
+    path = str(tmp_path / "chain.id")
+    with pytest.raises(shim.ShimError, match="timed out"):
+        shim.bootstrap_exchange_id(path, 1, 2, None, timeout_s=0.3)      # no rank 0
+    with pytest.raises(shim.ShimError, match="timed out"):
+        shim.bootstrap_exchange_id(path, 0, 2, bytes(128), timeout_s=0.3)  # rank 1's want file is there, rank 1 is not
+    with pytest.raises(shim.ShimError, match="bad argument"):
+        shim.bootstrap_exchange_id(path, 2, 2, None, timeout_s=0.1)
+
+
+def test_exchange_failure_keeps_nothing_queued_and_checks_capacity_first():
+    """a failing bchmc_eps_exchange must not leave this call's records queued (a retry would send them
+    twice), and the capacity check comes before anything is sent."""
+    import ctypes as C
+    calls = []
+
+    def broken(payload):
+        calls.append(len(payload))
+        raise RuntimeError("transport down")
+
+    c = eng.Comm(rank=0, world=2, allgather=broken)
+    assert c.info() == dict(world=2, rank=0, transport="custom")
+    with pytest.raises(eng.BchmcError):
+        c.exchange([(0.5, True, 3)])
+    assert calls == [eng.PACKET_BYTES] and c.pending() == 0
+    # too small an output array: refused before the transport is touched
+    out, who, got = (eng.EpsRecord * 8)(), (C.c_int * 8)(), C.c_int(0)
+    mine = (eng.EpsRecord * 1)()
+    rc = c.lib.bchmc_eps_exchange(c.h, mine, 1, out, who, 8, C.byref(got))
+    assert rc == 1 and len(calls) == 1 and c.pending() == 0 and b"capacity" in c.lib.bchmc_comm_last_error(c.h)
+    c.close()
+    solo = eng.Comm(rank=0, world=1)
+    assert solo.info()["transport"] == "none" and solo.exchange([(0.1, False, 2)]) == [(0, 0.1, False, 2)]
+    solo.close()

@@ -1,6 +1,7 @@
 """The host-array drop-in path (what barcode/main.cc reaches through the shim): staged copies, the single-pass
-bchmc_leapfrog whose energies bchmc_delta_hamiltonian reuses, the kinetic_term / psi entry points, mass re-upload by
-generation, and the RCCL transport of the record exchange (world size 1: all a one-GPU box can run)."""
+bchmc_leapfrog_dh (trajectory + the six energy terms; bchmc_delta_hamiltonian itself always evaluates), the
+kinetic_term / psi entry points, mass re-upload by generation, and the RCCL transport of the record exchange (world
+size 1: all a one-GPU box can run)."""
 import numpy as np
 import pytest
 
@@ -13,44 +14,157 @@ pytestmark = pytest.mark.gpu
                                 dict(likelihood=0, rsd_model=1), dict(likelihood=1, mass_type=5),
                                 dict(likelihood=3)],
                          ids=["gauss_rsd_fast", "poisson_fast", "poisson_rsd_generic", "mass_rs_generic", "grf_generic"])
-def test_delta_hamiltonian_after_leapfrog_reuses_the_trajectory_and_equals_the_explicit_evaluation(kw, monkeypatch):
+def test_leapfrog_dh_is_leapfrog_plus_delta_hamiltonian(kw):
+    """bchmc_leapfrog_dh: Hamiltonian_EoM and delta_Hamiltonian of the same four arrays in one pass (HMC.cc:455-459).
+    Its six terms are the ones the always-evaluating bchmc_delta_hamiltonian gives, and the oracle's."""
     c = Case(Nx=16, **kw)
     e = c.engine()
-    q1, p1, done = e.leapfrog(c.q0, c.p0, c.eps, 6)
-    dH_cached, t_cached = e.delta_hamiltonian(c.q0, c.p0, q1, p1)          # same arrays: answered from the trajectory
-    dH_full, t_full = e.delta_hamiltonian(c.q0.copy(), c.p0.copy(), q1.copy(), p1.copy())   # other arrays: evaluated
-    assert np.all(np.abs(t_cached - t_full) <= TOL_ENERGY * np.abs(t_full))
+    q1, p1, done, dH, t = e.leapfrog_dh(c.q0, c.p0, c.eps, 6)
+    q1b, p1b, doneb = e.leapfrog(c.q0, c.p0, c.eps, 6)                     # the plain trajectory
+    assert done == doneb == 6 and rel_l2(q1b, q1) < 1e-13 and rel_l2(p1b, p1) < 1e-13
+    dH_full, t_full = e.delta_hamiltonian(c.q0, c.p0, q1, p1)
+    assert np.all(np.abs(t - t_full) <= TOL_ENERGY * np.abs(t_full))
+    assert abs(dH - dH_full) <= 10 * TOL_ENERGY * np.abs(t_full).max()
     q1o, p1o, _ = c.oracle.Hamiltonian_EoM(c.q0, c.p0, c.eps, 6)
     dHo, to = c.oracle.delta_Hamiltonian(c.q0, c.p0, q1o, p1o)
     assert rel_l2(q1, q1o) < TOL_TRAJ_10 and rel_l2(p1, p1o) < TOL_TRAJ_10
-    assert np.all(np.abs(t_cached - to) <= 10 * TOL_ENERGY * np.abs(to))
-    # hd->deltaX after the pair of calls is psi(signalf)'s (HMC.cc:225), with or without the reuse
+    assert np.all(np.abs(t - to) <= 10 * TOL_ENERGY * np.abs(to))
+    # hd->deltaX after bchmc_leapfrog_dh is psi(signalf)'s (HMC.cc:225), as after the pair of calls
     if c.p.likelihood != 3:  # the GRF likelihood has no forward model
+        e.leapfrog_dh(c.q0, c.p0, c.eps, 6)
         dX = e.fetch("deltaX")
         c.oracle.psi(q1o)
         assert rel_l2(dX, c.oracle.get("deltaX")) < 1e-9
-    # a changed array is noticed (content fingerprint), not answered from the cache
-    q1b = q1.copy()
-    e.leapfrog(c.q0, c.p0, c.eps, 6)
-    dH2, t2 = e.delta_hamiltonian(c.q0, c.p0, q1b, p1)                     # q1b: different pointer
-    assert np.all(np.abs(t2 - t_full) <= TOL_ENERGY * np.abs(t_full))
-    monkeypatch.setenv("BCHMC_NO_DH_CACHE", "1")
-    q3, p3, _ = e.leapfrog(c.q0, c.p0, c.eps, 6)                           # plain trajectory, nothing cached
-    assert rel_l2(q3, q1) < 1e-13 and rel_l2(p3, p1) < 1e-13
+    # zero steps: the state comes back as it went in and both ends have the same energies
+    q1z, p1z, donez, dHz, tz = e.leapfrog_dh(c.q0, c.p0, c.eps, 0)
+    assert donez == 0 and rel_l2(q1z, c.q0) < 1e-13 and abs(dHz) <= 1e-9 * np.abs(tz).max()
+    assert np.all(np.abs(tz[:3] - t_full[:3]) <= TOL_ENERGY * np.abs(t_full[:3]))
     e.close()
 
 
-def test_fingerprint_catches_in_place_modification():
+def test_delta_hamiltonian_never_answers_from_an_earlier_call():
+    """VERDICT r2 / ADVICE r2: the C ABI keeps no energy cache.  Whatever happened before, bchmc_delta_hamiltonian
+    evaluates the arrays it is given against the inputs uploaded now."""
     c = Case(Nx=16, likelihood=1)
     e = c.engine()
     q0, p0 = c.q0.reshape(-1).copy(), c.p0.reshape(-1).copy()
-    q1, p1, _ = e.leapfrog(q0, p0, c.eps, 3)
-    _, t = e.delta_hamiltonian(q0, p0, q1, p1)
-    q1 *= 1.5                                                              # same pointer, new contents
+    q1, p1, _, _, t = e.leapfrog_dh(q0, p0, c.eps, 3)
+    # (1) a new mass between the trajectory and the question: both kinetic terms must follow it
+    e.upload(mass_f=2.0 * c.mass_f)
+    _, t_mass = e.delta_hamiltonian(q0, p0, q1, p1)
+    assert np.allclose(t_mass[[0, 3]], 0.5 * t[[0, 3]], rtol=1e-12)
+    assert np.allclose(t_mass[[1, 2, 4, 5]], t[[1, 2, 4, 5]], rtol=1e-12)
+    e.upload(mass_f=c.mass_f)
+    # (2) one element changed in place, away from every sampling stride a fingerprint could use
+    q1, p1, _, _, t = e.leapfrog_dh(q0, p0, c.eps, 3)
+    i = 1234
+    assert i % max(q1.size // 509, 1) != 0
+    q1[i] += 0.5
     _, t_mod = e.delta_hamiltonian(q0, p0, q1, p1)
     _, t_ref = e.delta_hamiltonian(q0.copy(), p0.copy(), q1.copy(), p1.copy())
-    assert np.allclose(t_mod, t_ref, rtol=1e-12) and not np.allclose(t_mod[3:], t[3:], rtol=1e-6)
+    assert np.allclose(t_mod, t_ref, rtol=1e-12)
+    assert abs(t_mod[4] - t[4]) > 1e-6 * abs(t[4]) and np.allclose(t_mod[:4], t[:4], rtol=1e-12)
+    # (3) an in-place trajectory (q1 is q0, p1 is p0) followed by the question about those arrays: both ends are the
+    # same arrays now, so dH is 0 -- not the trajectory's dH
+    qa, pa = q0.copy(), p0.copy()
+    e.leapfrog(qa, pa, c.eps, 3, out=(qa, pa))
+    dH_same, t_same = e.delta_hamiltonian(qa, pa, qa, pa)
+    assert np.allclose(t_same[:3], t_same[3:], rtol=1e-12) and abs(dH_same) <= 1e-10 * np.abs(t_same).max()
+    assert abs(t[3] - t[0]) > 1e-6 * abs(t[0])                             # ... whereas the trajectory's dK is not 0
     e.close()
+
+
+def test_host_calls_invalidate_a_pending_chain_proposal():
+    """bchmc_psi / bchmc_kinetic_term / bchmc_energies / ... overwrite the k-space buffers that hold the
+    resident chain's proposal; bchmc_chain_accept must then refuse instead of committing the wrong state."""
+    from barcode_amd.engine import BchmcError
+    c = Case(Nx=16, likelihood=1)
+    e = c.engine()
+    e.chain_set_state(c.q0)
+    e.chain_set_momenta(c.p0)
+    e.chain_attempt(c.eps, 3)
+    e.psi(c.truth)
+    with pytest.raises(BchmcError) as err:
+        e.chain_accept(True)
+    assert err.value.code == 9                                             # BCHMC_ERR_STATE
+    with pytest.raises(BchmcError):
+        e.chain_get_proposal()
+    # the chain itself is intact: the next attempt proposes, accepts and matches a chain that was never disturbed
+    dH, t, done = e.chain_attempt(c.eps, 3)
+    e.chain_accept(True)
+    x = e.chain_get_state()
+    e2 = c.engine()
+    e2.chain_set_state(c.q0)
+    e2.chain_set_momenta(c.p0)
+    dH2, t2, _ = e2.chain_attempt(c.eps, 3)
+    e2.chain_accept(True)
+    assert np.allclose(t, t2, rtol=1e-12) and rel_l2(x, e2.chain_get_state()) < 1e-13
+    e.close()
+    e2.close()
+
+
+def test_shim_reuses_the_trajectory_energies_only_under_its_stated_contract():
+    """bchmc_shim::Hamiltonian_EoM keeps bchmc_leapfrog_dh's six terms; delta_Hamiltonian answers from them only as the
+    NEXT call, about the same four arrays, with unchanged inputs (HMC.cc:455-459).  Everything else evaluates."""
+    from barcode_amd.shim import ShimHamil
+    c = Case(Nx=16, likelihood=1, rsd_model=1)
+    arrays = c.arrays()
+    arrays["mass_f"] = arrays["mass_f"].copy()
+    hd = ShimHamil(c.p, N_eps_fac=8.0, eps_fac=c.eps * 2, **arrays)
+    n = hd.numerical
+    q0, p0 = c.q0.reshape(-1).copy(), c.p0.reshape(-1).copy()
+    qf, pf = np.empty_like(q0), np.empty_like(p0)
+
+    def eom():
+        d = iter([0.3, 0.5])
+        hd.Hamiltonian_EoM(q0, p0, lambda: next(d), out=(qf, pf))
+
+    def terms():
+        return np.array([n.H_kin_i, n.psi_prior_i, n.psi_likeli_i, n.H_kin_f, n.psi_prior_f, n.psi_likeli_f])
+
+    eom()
+    assert hd.hd.eom.valid
+    dH = hd.delta_Hamiltonian(q0, p0, qf, pf)                               # reused
+    t_reuse = terms()
+    assert not hd.hd.eom.valid                                             # one use
+    dH2 = hd.delta_Hamiltonian(q0, p0, qf, pf)                              # evaluated
+    assert np.all(np.abs(terms() - t_reuse) <= TOL_ENERGY * np.abs(t_reuse)) and abs(dH - dH2) <= 1e-9 * np.abs(t_reuse).max()
+    dX_eval = hd.out("deltaX").copy()
+    eom()
+    hd.delta_Hamiltonian(q0, p0, qf, pf)
+    assert rel_l2(hd.out("deltaX"), dX_eval) < 1e-12                       # hd->deltaX is psi(signalf)'s either way
+    # other arrays -> evaluated (and correct for them)
+    eom()
+    hd.delta_Hamiltonian(q0, p0, qf.copy(), pf)
+    assert np.all(np.abs(terms() - t_reuse) <= TOL_ENERGY * np.abs(t_reuse))
+    # the mass changes between the two calls (mass_changed): both kinetic terms follow the new mass
+    eom()
+    hd._keep["mass_f"] *= 2.0                                              # the caller-owned array hd->mass_f points at
+    hd.mass_changed()
+    hd.delta_Hamiltonian(q0, p0, qf, pf)
+    assert np.allclose(terms()[[0, 3]], 0.5 * t_reuse[[0, 3]], rtol=1e-10)
+    hd._keep["mass_f"] *= 0.5
+    hd.mass_changed()
+    # another call in between ends the validity
+    eom()
+    hd.psi(c.truth)
+    assert not hd.hd.eom.valid
+    # mode 2: the contents are verified, a single changed element is noticed
+    hd.hd.reuse_eom_energies = 2
+    eom()
+    hd.delta_Hamiltonian(q0, p0, qf, pf)
+    assert np.all(np.abs(terms() - t_reuse) <= TOL_ENERGY * np.abs(t_reuse))
+    eom()
+    qf[4321] += 0.5
+    hd.delta_Hamiltonian(q0, p0, qf, pf)
+    assert abs(terms()[4] - t_reuse[4]) > 1e-6 * abs(t_reuse[4])
+    # mode 0: Hamiltonian_EoM is the plain trajectory, nothing is kept
+    hd.hd.reuse_eom_energies = 0
+    eom()
+    assert not hd.hd.eom.valid
+    hd.delta_Hamiltonian(q0, p0, qf, pf)
+    assert np.all(np.abs(terms() - t_reuse) <= TOL_ENERGY * np.abs(t_reuse))
+    hd.close()
 
 
 def test_kinetic_term_and_psi_entry_points():
@@ -133,3 +247,28 @@ def test_rccl_transport_world_size_one(tmp_path):
     assert log and log[-1]["accepted"] and hd.eps_records() == len(log)   # a single rank pools nothing
     hd.comm_release()
     hd.close()
+
+
+def test_bench_self_launch_two_ranks_reports_what_the_collective_saw():
+    """`python bench.py --gpus 2` without a launcher: the parent spawns two fresh rank processes (and asserts that it
+    never initialised the GPU itself), the ranks meet over gloo on one device (a one-GPU box cannot host two RCCL
+    ranks), and the JSON line says what the collective saw -- world, ranks, records -- so that a recorded N-GPU line
+    needs no inference about the rank count."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--single-device", "--backend",
+                        "gloo", "--nx", "32", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+                        "--no-kernel-profile"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["config"]["rehearsal_single_device"] is True
+    c = d["collective"]
+    assert c["backend"] == "gloo" and c["transport"] == "custom" and c["world_seen"] == 2
+    assert c["ranks_seen"] == [0, 1] and c["records"] == 2 and c["consistent_across_ranks"] and c["ok"]
+    assert d["config"]["steps_done"] == 3 and d["config"]["finite"]

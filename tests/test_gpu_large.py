@@ -99,9 +99,10 @@ def big():
 def test_config3_256cubed_eight_steps_and_energies_against_oracle(big):
     """BASELINE config 3 at the benchmarked size, against the oracle (OpenMP build, ~20 s of host time): the
     instantiations bench.py times -- k_step_boundary_x<double, 512, 4>, chunk = 2048, padded rows nhp = 136, 16384
-    tiles with 64-bit record offsets -- on an 8-step trajectory (first step: 3-D plans, six interior steps in planes
-    mode, last: 3-D plans; HMC.cc:251-369; 8 = the reference's largest default Neps, HMC.cc:260) and delta_Hamiltonian
-    (HMC.cc:209-248)."""
+    tiles with 64-bit record offsets -- on an 8-step trajectory (planes mode throughout: the force evaluation before
+    the first step and the first step run k_step_boundary_x<BX_FIRST> / <BX_LAST>, the six boundaries between steps the
+    interior variant, the last step <BX_LAST>; HMC.cc:251-369; 8 = the reference's largest default Neps, HMC.cc:260)
+    and delta_Hamiltonian (HMC.cc:209-248)."""
     from oracle.oracle import Oracle
     p, f, e, dX = big
     window, noise, nobs = inputs.mock_observations(p, dX)
