@@ -18,6 +18,7 @@
 #include "variants.hpp"  // NGP / CIC / TSC mass assignment and the calc_h 0 / 3 likelihood-force variants
 #include "rng.hpp"  // Philox4x32-10 momentum draw
 #include "tiles.hpp"  // Tile-sorted particle-mesh path: binning, scan, LDS scatter / gather kernels
+#include "tiles_low.hpp"  // NGP / CIC / TSC mass assignment and calc_h = 3's TSC interpolation on the same records
 #include "alpt.hpp"  // ALPT displacement (Lag2Eul_non_zeldovich)
 #include "spectrum.hpp"  // measure_spectrum
 #include "step_boundary_x.hpp"  // Planes mode: step boundary with the x passes of both transforms fused in

@@ -250,8 +250,9 @@ k_bin_direct(Geo g, PosPar pp, SphPar sp, TilePar tp, int nsuper, const T *__res
       if (key[m] < 0) continue;
       const int rank = hbase[slot[m]] + local[m];
       if (rank >= seg) {
-        ovf[0] = 1;  // benign race: every writer stores 1
-        ovf[1] = 1;  // sticky copy: the host enlarges the slots before the next trajectory
+        ovf[0] = 1;    // benign race: every writer stores 1
+        ovf[1] = seg;  // sticky copy for the host, stamped with the segment size that was too small (every writer of
+                       // a launch stores the same value; a stamp below the host's current size is a stale one)
       } else {
         const int t = key[m] / kOct;
         const long long dst = (long long)t * tp.cap + (long long)(key[m] - t * kOct) * seg + rank;
@@ -351,14 +352,17 @@ __device__ __forceinline__ int2 block_exclusive_scan2_1024(int a, int b, int2 *w
 __global__ void __launch_bounds__(1024)
 k_scan_tiles(TilePar tp, const int *__restrict__ cnt_direct, const int *__restrict__ cnt_fallback,
              const int *__restrict__ ovf, long long *__restrict__ off, long long *__restrict__ tend,
-             int *__restrict__ woff, int4 *__restrict__ oct, int *__restrict__ seg_out) {
+             int *__restrict__ woff, int4 *__restrict__ oct, int *__restrict__ seg_out, int *__restrict__ max_out) {
   // One tile per thread, ceil(ntiles / 1024) workgroups.  A workgroup first sums the counts of all tiles before its
   // own range (coalesced reads, at most 4 * ntiles bytes), then scans its 1024 tiles: every load and store is
   // coalesced, which a single workgroup striding over all tiles was not (33 us for 16384 tiles).
   __shared__ int2 wtot[16];
   __shared__ int2 s_base;
+  __shared__ int s_pop_max;
   const bool direct = !*ovf;
   const int T = tp.ntiles, tid = threadIdx.x;
+  if (tid == 0) s_pop_max = 0;  // read after the barriers of the scans below
+  int pop_max = 0;
   // record layout of this sort for the tile kernels (they must not read *ovf: the scatter clears it for the next
   // force evaluation while the gather still needs the layout): slots per octant segment, 0 = contiguous records
   if (blockIdx.x == 0 && tid == 0) *seg_out = direct ? tp.cap / kOct : 0;
@@ -394,6 +398,12 @@ k_scan_tiles(TilePar tp, const int *__restrict__ cnt_direct, const int *__restri
     woff[t] = eb;
     if (t == T - 1) woff[T] = eb + items(c);
     int4 lo = make_int4(0, 0, 0, 0), hi = make_int4(0, 0, 0, 0);
+    {
+      // largest (tile, octant) population of this binning -- the counters keep counting past a full segment, so the
+      // figure is exact also when it overflowed: what the host sizes the segments from (1.5x, at its next read-back)
+      const int4 a = cnt8[2 * t], b = cnt8[2 * t + 1];
+      pop_max = max(max(max(a.x, a.y), max(a.z, a.w)), max(max(b.x, b.y), max(b.z, b.w)));
+    }
     if (direct) {
       const int4 a = cnt8[2 * t], b = cnt8[2 * t + 1];
       lo = make_int4(0, a.x, a.x + a.y, a.x + a.y + a.z);
@@ -403,6 +413,12 @@ k_scan_tiles(TilePar tp, const int *__restrict__ cnt_direct, const int *__restri
     oct[2 * t] = lo;
     oct[2 * t + 1] = hi;
   }
+  // one atomic per workgroup on the host-read word, not one per tile
+#pragma unroll
+  for (int o = kWave / 2; o > 0; o >>= 1) pop_max = max(pop_max, __shfl_down(pop_max, o, kWave));
+  if ((tid & (kWave - 1)) == 0 && pop_max > 0) atomicMax(&s_pop_max, pop_max);
+  __syncthreads();
+  if (tid == 0 && s_pop_max > 0) atomicMax(max_out, s_pop_max);
 }
 
 // Fallback pass 3: write each particle's record (position, original index | flag) to its sorted slot.

@@ -155,7 +155,7 @@ def test_shim_reuses_the_trajectory_energies_only_under_its_stated_contract():
     hd.delta_Hamiltonian(q0, p0, qf, pf)
     assert np.all(np.abs(terms() - t_reuse) <= TOL_ENERGY * np.abs(t_reuse))
     eom()
-    qf[4321] += 0.5
+    qf[3211] += 0.5
     hd.delta_Hamiltonian(q0, p0, qf, pf)
     assert abs(terms()[4] - t_reuse[4]) > 1e-6 * abs(t_reuse[4])
     # mode 0: Hamiltonian_EoM is the plain trajectory, nothing is kept
