@@ -3,6 +3,8 @@
 #pragma once
 #include "common.hpp"
 
+#include <algorithm>
+
 namespace bchmc {
 
 // ======================================================================================================
@@ -44,47 +46,73 @@ __device__ __forceinline__ double findif_axis(const T *__restrict__ a, long long
                   (1.0 / 6) * ((double)a[o + ll * stride] - (double)a[o + rr * stride])));
 }
 
+// Workgroup -> z-rows for the two stencil passes.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8
+// share one), each XCD has its own L2, and the 4th-order stencils reach two rows (j) and two planes (i) either way: with
+// consecutive rows on consecutive workgroups every XCD fetched every row of the array for its y neighbours.  Here the
+// row slots a workgroup takes (b, b + gridDim, ...; gridDim a multiple of 8) all lie in ONE slab of n / 8 consecutive j
+// -- the same slab for all workgroups of an XCD -- so the y and x neighbours of a row are rows of the same XCD, but for
+// the two rows at each slab edge.  Pure scheduling: any mapping gives the same numbers.
+__device__ __forceinline__ void stencil_row(int slot, int n, int &i, int &j) {
+  if ((n & 7) == 0) {
+    const int slab = n >> 3, x = slot & 7, loc = slot >> 3;
+    j = x * slab + loc % slab;
+    i = loc / slab;
+  } else {
+    j = slot % n;
+    i = slot / n;
+  }
+}
+inline int stencil_grid(int n) {  // workgroups of the stencil passes: a multiple of 8, at most one per row
+  const long long rows = (long long)n * n;
+  return (int)std::max<long long>(std::min<long long>(rows, 4096) / 8 * 8, 8);
+}
+
 // First derivatives of Phi: g3[c] = d Phi / d x_c  (the `dummy` arrays of calc_m2v_mem, EqSolvers.cc:403-412)
 template <typename T>
 __global__ void __launch_bounds__(256) k_alpt_grad(Geo g, const T *__restrict__ phi, T *__restrict__ g3) {
   const double fac = g.n / (2. * g.L);
   const long long n = g.n;
-  for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < g.N; p += (long long)gridDim.x * blockDim.x) {
-    const int k = (int)(p % n);
-    const long long ij = p / n;
-    const int j = (int)(ij % n), i = (int)(ij / n);
-    g3[p] = (T)findif_axis<T>(phi, p, i, g.n, n * n, fac);
-    g3[p + g.N] = (T)findif_axis<T>(phi, p, j, g.n, n, fac);
-    g3[p + 2 * g.N] = (T)findif_axis<T>(phi, p, k, g.n, 1, fac);
+  for (int slot = blockIdx.x; slot < g.n * g.n; slot += gridDim.x) {
+    int i, j;
+    stencil_row(slot, g.n, i, j);
+    for (int k = threadIdx.x; k < g.n; k += blockDim.x) {
+      const long long p = k + n * (j + n * (long long)i);
+      g3[p] = (T)findif_axis<T>(phi, p, i, g.n, n * n, fac);
+      g3[p + g.N] = (T)findif_axis<T>(phi, p, j, g.n, n, fac);
+      g3[p + 2 * g.N] = (T)findif_axis<T>(phi, p, k, g.n, 1, fac);
+    }
   }
 }
 
-// delta(2) (EqSolvers.cc:415-421) and the two divergence sources (Lag2Eul.cc:199-226).  d1 holds delta(1) on
-// entry and the spherical-collapse source on exit; a2 receives D1 delta(1) - D2 delta(2).
+// delta(2) (EqSolvers.cc:415-421) and the two divergence sources (Lag2Eul.cc:199-226).  d1 holds delta(1); a_out
+// receives D1 delta(1) - D2 delta(2), b_out the spherical-collapse source.  Element-wise in (d1, a_out, b_out): either
+// output may be the d1 array itself.
 template <typename T>
 __global__ void __launch_bounds__(256)
-k_alpt_sources(Geo g, const T *__restrict__ g3, T *__restrict__ d1, T *__restrict__ a2, double D1, double D2) {
+k_alpt_sources(Geo g, const T *__restrict__ g3, const T *d1, T *a_out, T *b_out, double D1, double D2) {
   const double fac = g.n / (2. * g.L);
   const long long n = g.n;
   const T *gx = g3, *gy = g3 + g.N, *gz = g3 + 2 * g.N;
-  for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < g.N; p += (long long)gridDim.x * blockDim.x) {
-    const int k = (int)(p % n);
-    const long long ij = p / n;
-    const int j = (int)(ij % n), i = (int)(ij / n);
+  for (int slot = blockIdx.x; slot < g.n * g.n; slot += gridDim.x) {
+    int i, j;
+    stencil_row(slot, g.n, i, j);
+    for (int k = threadIdx.x; k < g.n; k += blockDim.x) {
+    const long long p = k + n * (j + n * (long long)i);
     const double xx = findif_axis<T>(gx, p, i, g.n, n * n, fac), xy = findif_axis<T>(gx, p, j, g.n, n, fac),
                  xz = findif_axis<T>(gx, p, k, g.n, 1, fac);
     const double yy = findif_axis<T>(gy, p, j, g.n, n, fac), yz = findif_axis<T>(gy, p, k, g.n, 1, fac);
     const double zz = findif_axis<T>(gz, p, k, g.n, 1, fac);
     const double m2v = xx * yy - xy * xy + xx * zz - xz * xz + yy * zz - yz * yz;
     const double dl = (double)d1[p];
-    a2[p] = (T)(D1 * dl - D2 * m2v);
+    a_out[p] = (T)(D1 * dl - D2 * m2v);
     const double psilin = -D1 * dl;
     double psisc;
     if (1. + 2. / 3. * psilin > 0.)
       psisc = 3. * (sqrt(1. + 2. / 3. * psilin) - 1.);
     else
       psisc = -3.;
-    d1[p] = (T)(-psisc);
+    b_out[p] = (T)(-psisc);
+    }
   }
 }
 
@@ -101,8 +129,11 @@ __global__ void k_alpt_kernel_table(Geo g, C2<T> *__restrict__ out, double smol)
   }
 }
 
-// Psi^_j = (k_j/k^2)(Im, -Re)[K A^ + (1 - K) B^] / N, Nyquist planes and k^2 <= 1e-14 -> 0
+// Psi^_j = P (k_j/k^2)(Im, -Re)[K A^ + (1 - K) B^] / N, Nyquist planes and k^2 <= 1e-14 -> 0
 // (theta2velcomp EqSolvers.cc:280-368 + convcomp convolution.cpp:327-377, combined).  A^ = Ck[0], B^ = Ck[1] on entry.
+// P = (1 + exp(-2 pi i (i + j + k) / n)) / 2 is cellboundcomp (massFunctions.cc:588-658: out[l] = (in[l] +
+// in[l - (1,1,1)]) / 2, periodic) by the shift theorem -- exact on a periodic grid, so the averaging pass over the three
+// real-space components is this factor (same numbers to round-off).
 template <typename T>
 __global__ void __launch_bounds__(256) k_alpt_mix(Geo g, C2<T> *Ck, double smol, double inv_wtot, double inv_n) {
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < g.Nhp;
@@ -120,29 +151,18 @@ __global__ void __launch_bounds__(256) k_alpt_mix(Geo g, C2<T> *Ck, double smol,
       // K o Psi^2LPT + Psi^SC - K o Psi^SC, in the reference's order of operations (Lag2Eul.cc:240-250)
       const double mr = (K * A.x + B.x) - K * B.x, mi = (K * A.y + B.y) - K * B.y;
       const double fac = inv_n / ksq;
-      const double fx = fac * kx, fy = fac * ky, fz = fac * kz;
-      ox = make_double2(fx * mi, fx * -mr);
-      oy = make_double2(fy * mi, fy * -mr);
-      oz = make_double2(fz * mi, fz * -mr);
+      double sn, cs;
+      sincospi(-2. * (double)((i + j + k) % g.n) / (double)g.n, &sn, &cs);
+      const double pr = 0.5 * (1. + cs), pi = 0.5 * sn;
+      const double ex = fac * mi, ey = fac * -mr;
+      const double er = ex * pr - ey * pi, ei = ex * pi + ey * pr;
+      ox = make_double2(kx * er, kx * ei);
+      oy = make_double2(ky * er, ky * ei);
+      oz = make_double2(kz * er, kz * ei);
     }
     st2<T>(Ck, idx, ox.x, ox.y);
     st2<T>(Ck, idx + g.Nhp, oy.x, oy.y);
     st2<T>(Ck, idx + 2 * g.Nhp, oz.x, oz.y);
-  }
-}
-
-// cellboundcomp (massFunctions.cc:588-658): out[l] = (in[l] + in[l - (1,1,1)]) / 2, periodic; 3 components
-template <typename T>
-__global__ void __launch_bounds__(256) k_alpt_cellbound(Geo g, const T *__restrict__ in3, T *__restrict__ out3) {
-  const long long n = g.n;
-  for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < g.N; p += (long long)gridDim.x * blockDim.x) {
-    const int k = (int)(p % n);
-    const long long ij = p / n;
-    const int j = (int)(ij % n), i = (int)(ij / n);
-    const int im = i > 0 ? i - 1 : g.n - 1, jm = j > 0 ? j - 1 : g.n - 1, km = k > 0 ? k - 1 : g.n - 1;
-    const long long m = km + n * (jm + n * (long long)im);
-#pragma unroll
-    for (int c = 0; c < 3; c++) out3[p + c * g.N] = (T)(0.5 * ((double)in3[m + c * g.N] + (double)in3[p + c * g.N]));
   }
 }
 

@@ -18,6 +18,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <climits>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -113,9 +114,17 @@ struct bchmc_handle {
   bool planes_ok = false;                        // plans + kernel available for this grid
   bool planes_c2r = false, planes_r2c = false;   // per force evaluation: which transform the next FFT call uses
   bool sort_direct = false;  // one-pass tile binning into fixed slots (two-pass sort as overflow fallback)
-  bool disp_alpt = false;    // Ck holds an ALPT displacement: forward_rest applies cellboundcomp after the C2R
+  rocfft_plan r2c2d_2 = nullptr, c2r2d_2 = nullptr;  // 2-D plans over 2 n planes: delta(1) | Phi and A | B of the ALPT model
+  bool alpt_plans_failed = false;
+  bool planes_c2r_once = false;  // Ck holds a displacement in planes space (launch_alpt): the next C2R is the 2-D one
+  bool alpt_pending = false;     // Ck[0], Ck[1] hold delta(1)^ | Phi^ planes left by k_step_boundary_x<ALPT>
   double alpt_wtot = 0.;     // kernelcomp's normalisation (sum of the real-space kernel), computed on first use
   bool std81 = false;  // standard 81-cell hull on 8 x 8 x 16 tiles with halo 2: fully unrolled scatter/gather kernels
+  unsigned short *stage_inv = nullptr;  // staged position -> cell of the scatter's LDS image (owner-blocked order)
+  unsigned *stage_tab = nullptr;  // k_stage_combine81's (neighbour, own cell, image cell) table, kStageCells entries
+  double *stage = nullptr;  // staging area of the scatter's LDS images, one 12 x 12 x 20 image per (tile, chunk) work item
+  bool rho_unread = false;  // set around an interior step's force evaluation: the combine pass need not store rho
+  bool staged = false;      // the images of the last scatter have not been summed into rho yet (k_stage_combine81)
   TilePar tp{};
   int *t_cnt = nullptr, *t_woff = nullptr;   // 9 ntiles + 2 (one-pass counts per (tile, octant), fallback counts per tile,
                                              // overflow flags), ntiles + 1
@@ -483,6 +492,62 @@ int poll_slots(bchmc_handle *h, uint64_t k) {
   return BCHMC_OK;
 }
 
+// Batched 2-D (y, z) real transforms over `batch` consecutive planes of the padded half-complex layout (planes mode).
+// Optional fast path: on failure both plans are left null and the batched 3-D plans carry the work.
+int make_plans_2d(bchmc_handle *h, size_t batch, rocfft_plan *r2c, rocfft_plan *c2r) {
+  const Geo &g = h->g;
+  const rocfft_precision prec = h->f32 ? rocfft_precision_single : rocfft_precision_double;
+  const size_t len2[2] = {(size_t)g.n, (size_t)g.n};
+  const size_t rs2[2] = {1, (size_t)g.n}, cs2[2] = {1, (size_t)g.nhp};
+  rocfft_plan_description f2 = nullptr, i2 = nullptr;
+  bool ok2 = rocfft_plan_description_create(&f2) == rocfft_status_success &&
+             rocfft_plan_description_create(&i2) == rocfft_status_success;
+  ok2 = ok2 && rocfft_plan_description_set_data_layout(f2, rocfft_array_type_real, rocfft_array_type_hermitian_interleaved,
+                                                       nullptr, nullptr, 2, rs2, (size_t)g.n * g.n, 2, cs2,
+                                                       (size_t)g.n * g.nhp) == rocfft_status_success;
+  ok2 = ok2 && rocfft_plan_description_set_data_layout(i2, rocfft_array_type_hermitian_interleaved, rocfft_array_type_real,
+                                                       nullptr, nullptr, 2, cs2, (size_t)g.n * g.nhp, 2, rs2,
+                                                       (size_t)g.n * g.n) == rocfft_status_success;
+  ok2 = ok2 && rocfft_plan_create(r2c, rocfft_placement_notinplace, rocfft_transform_type_real_forward, prec, 2, len2,
+                                  batch, f2) == rocfft_status_success;
+  ok2 = ok2 && rocfft_plan_create(c2r, rocfft_placement_notinplace, rocfft_transform_type_real_inverse, prec, 2, len2,
+                                  batch, i2) == rocfft_status_success;
+  if (f2) rocfft_plan_description_destroy(f2);
+  if (i2) rocfft_plan_description_destroy(i2);
+  if (ok2 && h->info) {
+    // plans made after bchmc_create: the shared work buffer may have to grow
+    size_t need = 0;
+    for (rocfft_plan p : {*r2c, *c2r}) {
+      size_t wb = 0;
+      if (rocfft_plan_get_work_buffer_size(p, &wb) != rocfft_status_success) ok2 = false;
+      need = std::max(need, wb);
+    }
+    if (ok2 && need > h->work_bytes) {
+      void *nw = nullptr;
+      (void)hipStreamSynchronize(h->stream);
+      if (hipMalloc(&nw, need) == hipSuccess &&
+          rocfft_execution_info_set_work_buffer(h->info, nw, need) == rocfft_status_success) {
+        if (h->work) (void)hipFree(h->work);
+        h->work = nw;
+        h->work_bytes = need;
+      } else {
+        if (nw) (void)hipFree(nw);
+        (void)hipGetLastError();
+        ok2 = false;
+      }
+    }
+  }
+  if (!ok2) {
+    for (rocfft_plan *pp : {r2c, c2r})
+      if (*pp) {
+        rocfft_plan_destroy(*pp);
+        *pp = nullptr;
+      }
+    return BCHMC_ERR_ROCFFT;
+  }
+  return BCHMC_OK;
+}
+
 // Sum kRedBlocks device partials on the host (synchronises the stream).
 int host_sum(bchmc_handle *h, const double *d_part, double *out) {
   HIPCHK(hipMemcpyAsync(h->h_part, d_part, kRedBlocks * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -661,7 +726,6 @@ struct Pipe {
     k_kick_drift_za<T, false><<<nblk_stride(h->g.Nhp), 256, 0, h->stream>>>(h->g, C(h->qk), C(h->pk), C(h->gk), nullptr,
                                                                           nullptr, C(h->Ck), 0., 0., c_za, ctl);
     HIPCHK(hipGetLastError());
-    h->disp_alpt = false;
     return BCHMC_OK;
   }
 
@@ -674,60 +738,126 @@ struct Pipe {
     return uses_alpt(h, rsd) ? launch_alpt(h, dq_factor) : launch_za(h, dq_factor);
   }
 
-  // ALPT displacement in k-space (Lag2Eul_non_zeldovich, Lag2Eul.cc:160-267); scratch: plike, rho, V, tC.
-  static int launch_alpt(bchmc_handle *h, double dq_factor) {
+  // kernelcomp: wtot = sum over the box of the inverse transform of the kernel table (= K(0) up to round-off)
+  static int alpt_norm(bchmc_handle *h) {
+    if (h->alpt_wtot != 0.) return BCHMC_OK;
+    ProfScope ps(h, BCHMC_K_OTHER);
+    k_alpt_kernel_table<T><<<nblk_stride(h->g.Nhp), 256, 0, h->stream>>>(h->g, C(h->tC), h->c.kth);
+    HIPCHK(hipGetLastError());
+    CHK(fft_exec(h, h->c2r1, h->tC, h->rho, BCHMC_K_FFT_C2R));
+    k_sum<T><<<kRedBlocks, 256, 0, h->stream>>>(R(h->rho), h->g.N, h->partA);
+    HIPCHK(hipGetLastError());
+    double v;
+    CHK(host_sum(h, h->partA, &v));
+    h->alpt_wtot = v / (double)h->g.N;
+    return BCHMC_OK;
+  }
+
+  // ALPT on the 2-D plans (alpt_x.hpp): the SPH-adjoint path's planes mode plus two plans over 2 n planes
+  static bool alpt_planes(bchmc_handle *h) {
+    if (!planes_everywhere(h) || env_on("BCHMC_NO_ALPT_PLANES")) return false;
+    if (!h->c2r2d_2 && !h->alpt_plans_failed) {
+      if (make_plans_2d(h, 2 * (size_t)h->g.n, &h->r2c2d_2, &h->c2r2d_2) != BCHMC_OK) h->alpt_plans_failed = true;
+    }
+    return h->c2r2d_2 != nullptr;
+  }
+
+  // ALPT displacement (Lag2Eul_non_zeldovich, Lag2Eul.cc:160-267), second part: from delta(1)^ and Phi^ in Ck[0], Ck[1]
+  // (full k-space, or planes space when `planes`) to Psi^ of the three components in Ck, cell-boundary average
+  // included.  Scratch: V, psi (planes) / plike, rho, V (3-D).
+  static int alpt_middle(bchmc_handle *h, bool planes) {
     const long long N = h->g.N, Nhp = h->g.Nhp;
-    const double smol = h->c.kth;
-    if (h->alpt_wtot == 0.) {
-      // kernelcomp: wtot = sum over the box of the inverse transform of the kernel table (= K(0) up to round-off)
-      ProfScope ps(h, BCHMC_K_OTHER);
-      k_alpt_kernel_table<T><<<nblk_stride(Nhp), 256, 0, h->stream>>>(h->g, C(h->tC), smol);
-      HIPCHK(hipGetLastError());
-      CHK(fft_exec(h, h->c2r1, h->tC, h->rho, BCHMC_K_FFT_C2R));
-      k_sum<T><<<kRedBlocks, 256, 0, h->stream>>>(R(h->rho), N, h->partA);
-      HIPCHK(hipGetLastError());
-      double v;
-      CHK(host_sum(h, h->partA, &v));
-      h->alpt_wtot = v / (double)N;
-    }
     CT *Ck = C(h->Ck);
-    {
-      ProfScope ps(h, BCHMC_K_KSPACE_DRIFT_ZA);
-      k_alpt_poisson<T><<<nblk_stride(Nhp), 256, 0, h->stream>>>(h->g, C(h->qk), Ck, Ck + Nhp, dq_factor / (double)N);
-      HIPCHK(hipGetLastError());
+    CHK(alpt_norm(h));
+    T *d1, *phi, *g3, *a_out, *b_out;
+    if (planes) {
+      // both transforms batched over 2 n planes: delta(1) -> V[0, N), Phi(1) -> V[N, 2N); first derivatives in psi
+      CHK(fft_exec(h, h->c2r2d_2, Ck, h->V, BCHMC_K_FFT_C2R));
+      d1 = R(h->V), phi = R(h->V) + N, g3 = R(h->psi), a_out = R(h->V), b_out = R(h->V) + N;
+    } else {
+      CHK(fft_exec(h, h->c2r1, Ck, h->plike, BCHMC_K_FFT_C2R));        // delta(1)
+      CHK(fft_exec(h, h->c2r1, Ck + Nhp, h->rho, BCHMC_K_FFT_C2R));    // Phi(1)
+      d1 = R(h->plike), phi = R(h->rho), g3 = R(h->V), a_out = R(h->rho), b_out = R(h->plike);
     }
-    CHK(fft_exec(h, h->c2r1, Ck, h->plike, BCHMC_K_FFT_C2R));        // delta(1)
-    CHK(fft_exec(h, h->c2r1, Ck + Nhp, h->rho, BCHMC_K_FFT_C2R));    // Phi(1)
     {
       ProfScope ps(h, BCHMC_K_OTHER);
-      k_alpt_grad<T><<<nblk_stride(N), 256, 0, h->stream>>>(h->g, R(h->rho), R(h->V));
-      k_alpt_sources<T><<<nblk_stride(N), 256, 0, h->stream>>>(h->g, R(h->V), R(h->plike), R(h->rho), h->c.D1, h->c.D2);
+      k_alpt_grad<T><<<stencil_grid(h->g.n), 256, 0, h->stream>>>(h->g, phi, g3);
+      k_alpt_sources<T><<<stencil_grid(h->g.n), 256, 0, h->stream>>>(h->g, g3, d1, a_out, b_out, h->c.D1, h->c.D2);
       HIPCHK(hipGetLastError());
     }
-    CHK(fft_exec(h, h->r2c1, h->rho, Ck, BCHMC_K_FFT_R2C));          // A^ = FFT[D1 delta(1) - D2 delta(2)]
-    CHK(fft_exec(h, h->r2c1, h->plike, Ck + Nhp, BCHMC_K_FFT_R2C));  // B^ = FFT[spherical-collapse source]
+    if (planes) {
+      CHK(fft_exec(h, h->r2c2d_2, h->V, Ck, BCHMC_K_FFT_R2C));         // A^, B^ of every (y, z) plane
+      ProfScope ps(h, BCHMC_K_KSPACE_DRIFT_ZA);
+      CHK(launch_alpt_mix_x(h));
+      h->planes_c2r_once = true;  // forward_rest: Psi^ needs only the (y, z) passes
+    } else {
+      CHK(fft_exec(h, h->r2c1, a_out, Ck, BCHMC_K_FFT_R2C));           // A^ = FFT[D1 delta(1) - D2 delta(2)]
+      CHK(fft_exec(h, h->r2c1, b_out, Ck + Nhp, BCHMC_K_FFT_R2C));     // B^ = FFT[spherical-collapse source]
+      ProfScope ps(h, BCHMC_K_KSPACE_DRIFT_ZA);
+      k_alpt_mix<T><<<nblk_stride(Nhp), 256, 0, h->stream>>>(h->g, Ck, h->c.kth, 1. / h->alpt_wtot, 1. / (double)N);
+      HIPCHK(hipGetLastError());
+    }
+    return BCHMC_OK;
+  }
+
+  // ALPT displacement from the current q^.
+  static int launch_alpt(bchmc_handle *h, double dq_factor) {
+    const double scale = dq_factor / (double)h->g.N;
+    if (alpt_planes(h)) {
+      {
+        ProfScope ps(h, BCHMC_K_KSPACE_DRIFT_ZA);
+        StepCtl nc{h->stop, h->steps_done, nullptr, 0., 0};
+        CHK((launch_boundary_x<BX_FIRST, true>(h, C(h->qk), nullptr, nullptr, nullptr, nullptr, 0., 0., 0., 0., scale,
+                                               nullptr, nc, nullptr, nullptr)));
+      }
+      return alpt_middle(h, true);
+    }
     {
       ProfScope ps(h, BCHMC_K_KSPACE_DRIFT_ZA);
-      k_alpt_mix<T><<<nblk_stride(Nhp), 256, 0, h->stream>>>(h->g, Ck, smol, 1. / h->alpt_wtot, 1. / (double)N);
+      k_alpt_poisson<T><<<nblk_stride(h->g.Nhp), 256, 0, h->stream>>>(h->g, C(h->qk), C(h->Ck), C(h->Ck) + h->g.Nhp, scale);
       HIPCHK(hipGetLastError());
     }
-    h->disp_alpt = true;
+    return alpt_middle(h, false);
+  }
+
+  static int launch_alpt_mix_x(bchmc_handle *h) {
+    constexpr int KB = 128 / (int)sizeof(CT);
+    constexpr int NT_BIG = sizeof(T) == 8 ? 256 : 512, NT_SMALL = NT_BIG / 4;
+    const int n = h->g.n, grid = n * (h->g.nhp / KB);
+    const size_t lds = ((size_t)n * KB + n / 2) * sizeof(CT);
+    const CT *tw = reinterpret_cast<const CT *>(h->xtw);
+#define BCHMC_LAUNCH_AX(NT, PER)                                                                                   \
+  do {                                                                                                             \
+    auto kern = k_alpt_mix_x<T, NT, PER>;                                                                          \
+    if (lds > 48 * 1024)                                                                                           \
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                 (int)lds));                                                                       \
+    kern<<<grid, NT, lds, h->stream>>>(h->g, h->log2n, tw, C(h->Ck), h->c.kth, 1. / h->alpt_wtot,                 \
+                                       1. / (double)h->g.N);                                                       \
+  } while (0)
+    switch (n) {
+      case 32: BCHMC_LAUNCH_AX(NT_SMALL, 4); break;
+      case 64: BCHMC_LAUNCH_AX(NT_SMALL, 8); break;
+      case 128: BCHMC_LAUNCH_AX(NT_BIG, 4); break;
+      case 256: BCHMC_LAUNCH_AX(2 * NT_BIG, 4); break;
+      case 512: BCHMC_LAUNCH_AX(2 * NT_BIG, 8); break;
+      default: return h->fail(BCHMC_ERR_STATE, "planes mode is not available for n = %d", n);
+    }
+#undef BCHMC_LAUNCH_AX
+    HIPCHK(hipGetLastError());
     return BCHMC_OK;
   }
 
   // C2R of the three displacement components, mass assignment, sum of rho.  Lag2Eul.cc:90-131 / 363-423.
-  static int forward_rest(bchmc_handle *h, int rsd) {
+  // defer_combine: the caller (like_force) sums the staged density images itself, fused with the likelihood partial
+  static int forward_rest(bchmc_handle *h, int rsd, bool defer_combine = false) {
+    const bool stage = h->stage && h->std81 && !h->fix && h->c.mk == 3 && h->tiled;
+    h->staged = false;
     if (rsd && !h->c.planepar) return h->fail(BCHMC_ERR_RSD_NOT_PLANEPAR, "non-plane-parallel RSD is not implemented");
-    if (h->disp_alpt) {
-      // ALPT: transform into V (free until the gather) and let cellboundcomp write the displacement proper
-      if (rsd) return h->fail(BCHMC_ERR_STATE, "ALPT displacement with the RSD routine");
-      CHK(fft_exec(h, h->c2r3, h->Ck, h->V, BCHMC_K_FFT_C2R));
-      ProfScope ps(h, BCHMC_K_OTHER);
-      k_alpt_cellbound<T><<<nblk_stride(h->g.N), 256, 0, h->stream>>>(h->g, R(h->V), R(h->psi));
-      HIPCHK(hipGetLastError());
-      h->disp_alpt = false;
-    } else {
-      CHK(fft_exec(h, h->planes_c2r ? h->c2r2d : h->c2r3, h->Ck, h->psi, BCHMC_K_FFT_C2R));
+    {
+      const bool planes = h->planes_c2r || h->planes_c2r_once;
+      h->planes_c2r_once = false;
+      CHK(fft_exec(h, planes ? h->c2r2d : h->c2r3, h->Ck, h->psi, BCHMC_K_FFT_C2R));
     }
     h->sorted_valid = false;
     bool rho_cleared = false;  // by k_bin_direct, on its way through the lattice
@@ -749,7 +879,8 @@ struct Pipe {
         const int nsuper = (nbricks + kBinPer - 1) / kBinPer;
         k_bin_direct<T><<<nsuper, BCHMC_BIN_THREADS, 0, h->stream>>>(h->g, pp, sp, h->tp, nsuper, R(h->psi), cnt1, ovf,
                                                        (RecQuad *)h->srec, R(h->V), h->rho_part,
-                                                       h->fix ? nullptr : R(h->rho), h->fix ? h->rho_fix : nullptr);
+                                                       (h->fix || stage) ? nullptr : R(h->rho),
+                                                       h->fix ? h->rho_fix : nullptr);
         rho_cleared = true;
       } else {
         HIPCHK(hipMemsetAsync(ovf, 1, 1, h->stream));  // non-zero flag: two-pass sort only
@@ -768,7 +899,7 @@ struct Pipe {
       // fixed point (deterministic mode): scale = 2^46 / largest single contribution (W(0) = 1/(pi h^3) for the SPH
       // kernel, 1 for NGP / CIC / TSC weights)
       const double fix_scale = h->c.mk == 3 ? 70368744177664. / sp.w_norm : 70368744177664.;
-      if (rho_cleared) {
+      if (rho_cleared || stage) {  // staged images: every cell of rho is written by the combine pass
       } else if (h->fix) {
         HIPCHK(hipMemsetAsync(h->rho_fix, 0, h->g.N * sizeof(long long), h->stream));
       } else {
@@ -794,12 +925,18 @@ struct Pipe {
                 h->g, sp, h->tp, (const RecQuad *)h->srec, h->t_off, h->t_end, h->t_woff,
                 h->t_oct, h->t_seg, h->rho_fix, h->rho_part, h->t_cnt,
                 (kOct + 1) * h->tp.ntiles + 1, fix_scale);
+          else if (stage)
+            k_scatter_tile81<T, 12, 20, false, true><<<grid, 256, tile_lds(h, 0, sizeof(double)), h->stream>>>(
+                h->g, sp, h->tp, (const RecQuad *)h->srec, h->t_off, h->t_end, h->t_woff,
+                h->t_oct, h->t_seg, R(h->rho), h->rho_part, h->t_cnt,
+                (kOct + 1) * h->tp.ntiles + 1, fix_scale, h->stage, h->stage_inv);
           else
             k_scatter_tile81<T, 12, 20, false><<<grid, 256, tile_lds(h, 0, sizeof(double)), h->stream>>>(
                 h->g, sp, h->tp, (const RecQuad *)h->srec, h->t_off, h->t_end, h->t_woff,
                 h->t_oct, h->t_seg, R(h->rho), h->rho_part, h->t_cnt,
                 (kOct + 1) * h->tp.ntiles + 1, fix_scale);
           h->cnt_clean = true;
+          h->staged = stage;
         } else if (h->fix) {
           k_scatter_tile<T, true><<<grid, 256, tile_lds(h, ncol, sizeof(double)), h->stream>>>(
               h->g, sp, h->tp, h->hull, ncol, (const RecQuad *)h->srec, h->t_off, h->t_end,
@@ -851,8 +988,33 @@ struct Pipe {
       k_sum<T><<<kRedBlocks, 256, 0, h->stream>>>(R(h->rho), h->g.N, h->rho_part);
       HIPCHK(hipGetLastError());
     }
+    if (h->staged && !defer_combine) CHK(combine_staged(h, false));
     h->have_eval = true;
     h->last_rsd = rsd;
+    return BCHMC_OK;
+  }
+
+  // rho (and, with `like`, the likelihood partial) from the staged images of the last scatter.  Interior steps of a
+  // trajectory (h->rho_unread) skip the store of rho itself: nothing reads it before the next scatter.
+  static int combine_staged(bchmc_handle *h, bool like) {
+    ProfScope ps(h, BCHMC_K_MEAN_PARTIAL);
+    const int grid = std::min(h->tp.ntiles, 4096);
+    const T *nobs = R(h->in_arr[BCHMC_F_NOBS]), *noise = R(h->in_arr[BCHMC_F_NOISE]), *window = R(h->in_arr[BCHMC_F_WINDOW]);
+    if (like && h->rho_unread)
+      k_stage_combine81<T, true, false><<<grid, 256, 0, h->stream>>>(h->g, h->tp, make_like(h), h->stage, h->stage_tab,
+                                                                     h->t_woff, R(h->rho), h->rho_part, nobs, noise,
+                                                                     window, R(h->plike));
+    else if (like)
+      k_stage_combine81<T, true, true><<<grid, 256, 0, h->stream>>>(h->g, h->tp, make_like(h), h->stage, h->stage_tab,
+                                                                    h->t_woff, R(h->rho), h->rho_part, nobs, noise,
+                                                                    window, R(h->plike));
+    else
+      k_stage_combine81<T, false, true><<<grid, 256, 0, h->stream>>>(h->g, h->tp, make_like(h), h->stage, h->stage_tab,
+                                                                     h->t_woff, R(h->rho), h->rho_part, nullptr, nullptr,
+                                                                     nullptr, nullptr);
+    HIPCHK(hipGetLastError());
+    h->staged = false;
+    h->have_eval = !(like && h->rho_unread);  // without rho there is no deltaX to fetch
     return BCHMC_OK;
   }
 
@@ -870,7 +1032,9 @@ struct Pipe {
       return h->fail(BCHMC_ERR_ARG, "calc_h = %d is not a valid value (0..3)", h->c.calc_h);
     }
     const long long N = h->g.N, Nh = h->g.Nhp;
-    {
+    if (h->staged) {
+      CHK(combine_staged(h, true));  // rho and the likelihood partial in one pass over the staged images
+    } else {
       ProfScope ps(h, BCHMC_K_MEAN_PARTIAL);
       k_partial_like<T><<<nblk_stride(N), 256, 0, h->stream>>>(h->g, make_like(h), R(h->rho), h->rho_part,
                                                                R(h->in_arr[BCHMC_F_NOBS]), R(h->in_arr[BCHMC_F_NOISE]),
@@ -945,7 +1109,7 @@ struct Pipe {
       if (h->tiled && h->sorted_valid) {
         const int grid = h->tp.ntiles + (int)(N / h->tp.chunk) + 1;
         if (h->std81)
-          k_gather_tile81<T, 12, 20><<<grid, 256, tile_lds(h, 0, sizeof(T)), h->stream>>>(
+          k_gather_tile81<T, 12, 20><<<grid, 256, tile_lds(h, 0, sizeof(T)) * (20 + BCHMC_GATHER_LZPAD) / 20, h->stream>>>(
               h->g, hp, h->tp, h->last_rsd, (RecQuad *)h->srec, h->t_off, h->t_end, h->t_woff,
               h->t_oct, h->t_seg, R(h->plike), R(h->V));
         else
@@ -992,8 +1156,13 @@ struct Pipe {
       *b = h->c.grad_psi_likeli_factor;
       return BCHMC_OK;
     }
-    if (!pre_za) CHK(displacement(h, h->c.deltaQ_factor, h->c.rsd_model));
-    CHK(forward_rest(h, h->c.rsd_model));
+    if (!pre_za) {
+      CHK(displacement(h, h->c.deltaQ_factor, h->c.rsd_model));
+    } else if (h->alpt_pending) {
+      h->alpt_pending = false;
+      CHK(alpt_middle(h, true));  // delta(1)^ | Phi^ planes left by k_step_boundary_x<ALPT> -> Psi^ planes
+    }
+    CHK(forward_rest(h, h->c.rsd_model, /*defer_combine=*/true));
     CHK(like_force(h, like_mode));
     double norm = -1.;  // zeldovich_norm, HMC_models.cc:458-461
     norm *= h->c.deltaQ_factor;
@@ -1092,18 +1261,26 @@ struct Pipe {
     double b = 0.;
     // 0) gradient at t = 0 (HMC.cc:279-280)
     // the k-space kernels produce the Zel'dovich Psi^ as a by-product; the ALPT model needs its own pipeline
-    const bool fused_za = (h->c.likelihood != 3) && !uses_alpt(h, h->c.rsd_model);
-    const double c_za = -h->c.D1 * h->c.deltaQ_factor / (double)h->g.N;
-    const bool fused = fused_za && !h->mass_rs && !env_on("BCHMC_NO_FUSE");
+    // ... on the 2-D plans (alpt_planes) the step boundary leaves that pipeline's two input fields instead of Psi^
+    const bool alpt = uses_alpt(h, h->c.rsd_model) && h->c.likelihood != 3;
+    const bool alpt_x = alpt && !h->mass_rs && !env_on("BCHMC_NO_FUSE") && alpt_planes(h);
+    const bool fused_za = (h->c.likelihood != 3) && !alpt;
+    const double c_za = alpt_x ? h->c.deltaQ_factor / (double)h->g.N : -h->c.D1 * h->c.deltaQ_factor / (double)h->g.N;
+    const bool fused = (fused_za || alpt_x) && !h->mass_rs && !env_on("BCHMC_NO_FUSE");
     if (!g0_in) {
       if (fused && planes_everywhere(h)) {
         // the same evaluation on the 2-D plans: Psi^ with its inverse x passes, V^ assembled after forward x passes
         StepCtl nc{h->stop, h->steps_done, nullptr, 0., 0};
         {
           ProfScope ps(h, BCHMC_K_KSPACE_DRIFT_ZA);
-          CHK(launch_boundary_x<BX_FIRST>(h, C(h->qk), nullptr, nullptr, nullptr, nullptr, 0., 0., 0., 0., c_za, nullptr,
-                                          nc, nullptr, nullptr));
+          if (alpt_x)
+            CHK((launch_boundary_x<BX_FIRST, true>(h, C(h->qk), nullptr, nullptr, nullptr, nullptr, 0., 0., 0., 0., c_za,
+                                                   nullptr, nc, nullptr, nullptr)));
+          else
+            CHK(launch_boundary_x<BX_FIRST>(h, C(h->qk), nullptr, nullptr, nullptr, nullptr, 0., 0., 0., 0., c_za, nullptr,
+                                            nc, nullptr, nullptr));
         }
+        h->alpt_pending = alpt_x;
         h->planes_c2r = h->planes_r2c = true;
         const int rc = force_sources(h, true, &like_mode, &b);
         h->planes_c2r = h->planes_r2c = false;
@@ -1127,7 +1304,7 @@ struct Pipe {
 
     const double *wM = h->mass_fs ? h->wM : nullptr;
     const double guard_limit = 1e50 * (double)h->g.N;
-    if (fused) return trajectory_fused(h, eps, neps, tap, a, wM, c_za, g_first);
+    if (fused) return trajectory_fused(h, eps, neps, tap, a, wM, c_za, g_first, alpt_x);
     for (uint64_t s = 0; s < neps; s++) {
       StepCtl ctl{h->stop, h->steps_done, s > 0 ? h->guard + (s - 1) : nullptr, guard_limit, s};
       if (!h->mass_rs) {
@@ -1159,7 +1336,7 @@ struct Pipe {
   }
 
   // k_step_boundary_x for this grid: n == PER * NT / KB with KB = 8 (fp64, NT = 256) or 16 (fp32, NT = 512)
-  template <int MODE = BX_INTERIOR>
+  template <int MODE = BX_INTERIOR, bool ALPT = false>
   static int launch_boundary_x(bchmc_handle *h, const CT *qi, const CT *pi, CT *qo, CT *po, const double *wM, double a,
                                double b, double half_eps, double eps, double c_za, double *guard_slot, StepCtl ctl,
                                const CT *g_in = nullptr, CT *g_out = nullptr) {
@@ -1170,7 +1347,7 @@ struct Pipe {
     const CT *tw = reinterpret_cast<const CT *>(h->xtw);
 #define BCHMC_LAUNCH_X(NT, PER)                                                                                    \
   do {                                                                                                             \
-    auto kern = k_step_boundary_x<T, NT, PER, MODE>;                                                               \
+    auto kern = k_step_boundary_x<T, NT, PER, MODE, ALPT>;                                                         \
     if (lds > 48 * 1024)                                                                                           \
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                  (int)lds));                                                                       \
@@ -1193,7 +1370,7 @@ struct Pipe {
   // The same trajectory with every interior "second half kick | first half kick + drift + Zel'dovich" pair done by
   // one kernel (k_step_boundary) on ping-pong state buffers.  Used for k-space masses and forward-model likelihoods.
   static int trajectory_fused(bchmc_handle *h, double eps, uint64_t neps, const Tap *tap, double a, const double *wM,
-                              double c_za, const void *g_first) {
+                              double c_za, const void *g_first, bool alpt_x = false) {
     const double guard_limit = 1e50 * (double)h->g.N;
     if (!h->qk2) {
       CHK(dev_alloc_bytes(h, &h->qk2, 2 * (size_t)h->g.Nhp * sizeof(T)));
@@ -1207,7 +1384,10 @@ struct Pipe {
     {
       StepCtl ctl{h->stop, h->steps_done, nullptr, guard_limit, 0};
       ProfScope ps(h, BCHMC_K_KSPACE_DRIFT_ZA);
-      if (ends) {
+      if (ends && alpt_x) {
+        CHK((launch_boundary_x<BX_FIRST, true>(h, C(q0), C(p0), C(q0), C(p0), wM, 0., 0., 0.5 * eps, eps, c_za, nullptr,
+                                               ctl, C(g_first), nullptr)));
+      } else if (ends) {
         CHK(launch_boundary_x<BX_FIRST>(h, C(q0), C(p0), C(q0), C(p0), wM, 0., 0., 0.5 * eps, eps, c_za, nullptr, ctl,
                                         C(g_first), nullptr));
       } else {
@@ -1221,7 +1401,11 @@ struct Pipe {
       if (h->slot_watch && h->tiled && h->sort_direct && s > 0 && s % kSlotPoll == 0) CHK(poll_slots(h, s / kSlotPoll));
       h->planes_c2r = planes && (s > 0 || ends);  // Psi^ left by k_step_boundary_x still needs only the (y, z) passes
       h->planes_r2c = planes && (!last || ends);  // ... and V^ for it gets only those
+      h->alpt_pending = alpt_x;                    // ... or delta(1)^ | Phi^ planes for the ALPT pipeline
+      h->rho_unread = !last && h->c.calc_h != 0 && !env_on("BCHMC_KEEP_RHO");  // rho of an interior step is read by
+                                                                                   // nobody (calc_h 0: k_overdens does)
       const int rc = force_sources(h, true, &like_mode, &b);
+      h->rho_unread = false;
       const bool xmode = h->planes_r2c && like_mode == 0;
       h->planes_c2r = h->planes_r2c = false;
       CHK(rc);
@@ -1236,6 +1420,10 @@ struct Pipe {
         k_step_boundary<T, true><<<nblk_stride(h->g.Nhp), 256, 0, h->stream>>>(
             h->g, C(h->Ck), C(qi), C(pi), C(qi), C(pi), C(h->gk), h->wS, wM, a, b, like_mode, 0.5 * eps, eps, c_za,
             h->guard + s, ctl);
+      } else if (xmode && alpt_x) {
+        CHK((launch_boundary_x<BX_INTERIOR, true>(h, C(qi), C(pi), C(qo), C(po), wM, a, b, 0.5 * eps, eps, c_za,
+                                                  h->guard + s, ctl)));
+        cur ^= 1;
       } else if (xmode) {
         CHK(launch_boundary_x(h, C(qi), C(pi), C(qo), C(po), wM, a, b, 0.5 * eps, eps, c_za, h->guard + s, ctl));
         cur ^= 1;
@@ -1747,33 +1935,7 @@ int bchmc_create(const bchmc_config *cfg, bchmc_handle **out) {
       while ((1 << l2) < g.n) l2++;
       if ((1 << l2) == g.n && g.n >= 32 && g.n <= 512 && g.nhp % KB == 0) {
         h->log2n = l2;
-        const size_t len2[2] = {(size_t)g.n, (size_t)g.n};
-        const size_t rs2[2] = {1, (size_t)g.n}, cs2[2] = {1, (size_t)g.nhp};
-        // optional fast path: if rocFFT refuses the 2-D strided plans, the batched 3-D plans carry every step
-        rocfft_plan_description f2 = nullptr, i2 = nullptr;
-        bool ok2 = rocfft_plan_description_create(&f2) == rocfft_status_success &&
-                   rocfft_plan_description_create(&i2) == rocfft_status_success;
-        ok2 = ok2 && rocfft_plan_description_set_data_layout(f2, rocfft_array_type_real,
-                                                             rocfft_array_type_hermitian_interleaved, nullptr, nullptr, 2,
-                                                             rs2, (size_t)g.n * g.n, 2, cs2,
-                                                             (size_t)g.n * g.nhp) == rocfft_status_success;
-        ok2 = ok2 && rocfft_plan_description_set_data_layout(i2, rocfft_array_type_hermitian_interleaved,
-                                                             rocfft_array_type_real, nullptr, nullptr, 2, cs2,
-                                                             (size_t)g.n * g.nhp, 2, rs2,
-                                                             (size_t)g.n * g.n) == rocfft_status_success;
-        ok2 = ok2 && rocfft_plan_create(&h->r2c2d, rocfft_placement_notinplace, rocfft_transform_type_real_forward, prec,
-                                        2, len2, 3 * (size_t)g.n, f2) == rocfft_status_success;
-        ok2 = ok2 && rocfft_plan_create(&h->c2r2d, rocfft_placement_notinplace, rocfft_transform_type_real_inverse, prec,
-                                        2, len2, 3 * (size_t)g.n, i2) == rocfft_status_success;
-        if (f2) rocfft_plan_description_destroy(f2);
-        if (i2) rocfft_plan_description_destroy(i2);
-        if (!ok2) {
-          for (rocfft_plan *pp : {&h->r2c2d, &h->c2r2d})
-            if (*pp) {
-              rocfft_plan_destroy(*pp);
-              *pp = nullptr;
-            }
-        }
+        const bool ok2 = make_plans_2d(h, 3 * (size_t)g.n, &h->r2c2d, &h->c2r2d) == BCHMC_OK;
         // twiddles exp(-2 pi i r / n), r < n / 2, from the host's libm
         std::vector<double> tw(g.n);
         for (int r = 0; r < g.n / 2; r++) {
@@ -1791,9 +1953,14 @@ int bchmc_create(const bchmc_config *cfg, bchmc_handle **out) {
           HIPCHK(hipStreamSynchronize(h->stream));
         }
         h->planes_ok = ok2;
+        // the ALPT model's planes pipeline transforms two fields at a time (alpt_x.hpp): plans made here, not inside
+        // the first trajectory
+        if (ok2 && !cfg->rsd_model && cfg->sfmodel != 1 && cfg->calc_h == 2 && cfg->mk == 3 &&
+            make_plans_2d(h, 2 * (size_t)g.n, &h->r2c2d_2, &h->c2r2d_2) != BCHMC_OK)
+          h->alpt_plans_failed = true;
       }
     }
-    for (rocfft_plan p : {h->r2c1, h->c2r1, h->r2c3, h->c2r3, h->r2c2d, h->c2r2d}) {
+    for (rocfft_plan p : {h->r2c1, h->c2r1, h->r2c3, h->c2r3, h->r2c2d, h->c2r2d, h->r2c2d_2, h->c2r2d_2}) {
       if (!p) continue;
       size_t wb = 0;
       FFTCHK(rocfft_plan_get_work_buffer_size(p, &wb));
@@ -1918,6 +2085,48 @@ int bchmc_create(const bchmc_config *cfg, bchmc_handle **out) {
           CHK(dev_alloc(h, &h->t_woff, (size_t)tp.ntiles + 1));
           CHK(dev_alloc(h, &h->t_rank, N));
           CHK(dev_alloc_bytes(h, &h->srec, nrec * 4 * e));
+          // staging area for the density images of the unrolled scatter (k_scatter_tile81<STAGE>): one image per
+          // possible work item, 566 MB at 256^3.  Opt-in (BCHMC_STAGE=1): measured a wash against the flush through
+          // global atomics -- scatter 0.92 -> 0.83 ms, but the combine pass that replaces k_partial_like 0.13 -> 0.25 ms
+          // (profiles/r03_ab_stage.txt)
+          if (h->std81 && !h->fix && env_on("BCHMC_STAGE")) {
+            const size_t items = (size_t)tp.ntiles + N / (size_t)tp.chunk + 1;
+            CHK(dev_alloc(h, &h->stage, items * (size_t)tp.lx * tp.ly * tp.lz));
+            // which tile owns each cell of a 12 x 12 x 20 image: direction delta from the image's tile to the owner,
+            // the owner's cell; staged position = cells grouped by owner (27 blocks), z fastest inside a block
+            struct Cellinfo { int block, own, img; };
+            std::vector<Cellinfo> cells;
+            for (int lx = 0; lx < 12; lx++)
+              for (int ly = 0; ly < 12; ly++)
+                for (int lz = 0; lz < 20; lz++) {
+                  const int ex = lx < 2 ? -1 : (lx >= 10 ? 1 : 0), ey = ly < 2 ? -1 : (ly >= 10 ? 1 : 0),
+                            ez = lz < 2 ? -1 : (lz >= 18 ? 1 : 0);
+                  const int x = lx - 2 - 8 * ex, y = ly - 2 - 8 * ey, z = lz - 2 - 16 * ez;  // owner-local cell
+                  cells.push_back({(ez + 1) + 3 * ((ey + 1) + 3 * (ex + 1)), z + 16 * (y + 8 * x), lz + 20 * (ly + 12 * lx)});
+                }
+            std::stable_sort(cells.begin(), cells.end(), [](const Cellinfo &a, const Cellinfo &b) {
+              return a.block != b.block ? a.block < b.block : a.own < b.own;
+            });
+            std::vector<unsigned> tab;
+            std::vector<unsigned short> inv;
+            for (size_t pos = 0; pos < cells.size(); pos++) {
+              // the owner sees the image's tile at -delta: neighbour index 26 - block; one entry per pair of cells
+              // (every block is a whole number of z-adjacent pairs: its z extent is 16 or 2 cells from an even z)
+              if (pos % 2 == 0) {
+                if (cells[pos + 1].block != cells[pos].block || cells[pos + 1].own != cells[pos].own + 1)
+                  return h->fail(BCHMC_ERR_STATE, "stage table: position %zu does not start a pair", pos);
+                tab.push_back(stage_entry(26 - cells[pos].block, cells[pos].own, (int)pos));
+              }
+              inv.push_back((unsigned short)cells[pos].img);
+            }
+            CHK(dev_alloc(h, &h->stage_inv, inv.size()));
+            HIPCHK(hipMemcpyAsync(h->stage_inv, inv.data(), inv.size() * sizeof(unsigned short), hipMemcpyHostToDevice,
+                                  h->stream));
+            if ((int)tab.size() != kStagePairs) return h->fail(BCHMC_ERR_STATE, "stage table has %zu entries", tab.size());
+            CHK(dev_alloc(h, &h->stage_tab, tab.size()));
+            HIPCHK(hipMemcpyAsync(h->stage_tab, tab.data(), tab.size() * sizeof(unsigned), hipMemcpyHostToDevice, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+          }
         }
       }
     }
@@ -1935,12 +2144,12 @@ void bchmc_destroy(bchmc_handle *h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   prof_collect(h);
   for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
-  for (rocfft_plan p : {h->r2c1, h->c2r1, h->r2c3, h->c2r3, h->r2c2d, h->c2r2d})
+  for (rocfft_plan p : {h->r2c1, h->c2r1, h->r2c3, h->c2r3, h->r2c2d, h->c2r2d, h->r2c2d_2, h->c2r2d_2})
     if (p) rocfft_plan_destroy(p);
   if (h->info) rocfft_execution_info_destroy(h->info);
   void *ptrs[] = {h->work,  h->wS,       h->wM,    h->qk,    h->pk,   h->gk,     h->Ck,         h->tC,   h->psi,
                   h->V,     h->rho,      h->plike, h->ioq,   h->iop,  h->gprior, h->glike,      h->conv, h->convF,
-                  h->dstage, h->rho_fix, h->fix_sat, h->spec_bins, h->cq, h->cp, h->cg, h->qk2, h->pk2, h->xtw, h->part6, h->rho_part, h->partA, h->guard, h->stop, h->steps_done, h->hull,  h->t_cnt, h->t_off,
+                  h->dstage, h->rho_fix, h->fix_sat, h->stage, h->stage_tab, h->stage_inv, h->spec_bins, h->cq, h->cp, h->cg, h->qk2, h->pk2, h->xtw, h->part6, h->rho_part, h->partA, h->guard, h->stop, h->steps_done, h->hull,  h->t_cnt, h->t_off,
                   h->t_woff, h->t_oct, h->t_seg, h->t_end, h->t_rank,  h->srec};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
@@ -2279,6 +2488,19 @@ int bchmc_philox_kat(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[
   (void)hipFree(d);
   if (e != hipSuccess) return BCHMC_ERR_HIP;
   out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
+  return BCHMC_OK;
+}
+
+int bchmc_tile_info(bchmc_handle *h, int32_t out[8]) {
+  if (!h || !out) return BCHMC_ERR_ARG;
+  out[0] = h->tiled ? 1 : 0;
+  out[1] = h->sort_direct ? 1 : 0;
+  out[2] = h->tp.cap;
+  out[3] = (int32_t)std::min<long long>(h->cap_alloc, INT32_MAX);
+  out[4] = h->slot_watch ? 1 : 0;
+  out[5] = h->stage ? 1 : 0;
+  out[6] = h->std81 ? 1 : 0;
+  out[7] = (h->c2r2d_2 != nullptr) ? 1 : 0;
   return BCHMC_OK;
 }
 

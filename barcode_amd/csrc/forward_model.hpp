@@ -212,6 +212,39 @@ __device__ __forceinline__ double pow_bias(double x, const LikePar &lp) {
   return lp.bias_is_identity ? x : pow(x, lp.biasE);
 }
 
+// One cell of partial_f_delta_x_log_like (gaussian_independent.cpp:24-42, poissonian.cpp:19-34,
+// lognormal_independent.cpp:40-55) from its operands: w = window, nv = nobs, sv = noise (unused by the Poissonian).
+__device__ __forceinline__ double partial_like_value(const LikePar &lp, double dX, double w, double nv, double sv) {
+  double out = 0.;
+  if (lp.likelihood == 1) {
+    const double Lambda = w * lp.rho_c * pow_bias(1. + lp.biasP * dX, lp);
+    if ((w > 0.) && (Lambda > 0.0)) out = (nv - Lambda) / (sv * sv);
+  } else if (lp.likelihood == 0) {
+    const double dens = 1. + lp.biasP * dX;
+    if ((w > 0.0) && (dens > 0.0)) {
+      const double Lambda = w * lp.rho_c * pow_bias(dens, lp);
+      const double dpow = lp.bias_is_identity ? 1. : pow(dens, lp.biasE - 1);
+      out = (1 - nv / Lambda) * lp.rho_c * lp.biasE * lp.biasP * dpow;
+    }
+  } else {  // 2: log-normal
+    if (w > 0.) {
+      const double Lambda = log(lp.rho_c * pow_bias(1. + lp.biasP * dX, lp));
+      out = (nv - Lambda) / (sv * sv);
+    }
+  }
+  return out;
+}
+
+// The three data operands of a cell, all requested before any of them is used (streaming hints: read once per step).
+template <typename T>
+__device__ __forceinline__ void like_operands(const LikePar &lp, long long i, const T *__restrict__ nobs,
+                                              const T *__restrict__ noise, const T *__restrict__ window, double &w,
+                                              double &nv, double &sv) {
+  w = (double)stream_load<BCHMC_NT_LIKE != 0>(window + i);
+  nv = (double)stream_load<BCHMC_NT_LIKE != 0>(nobs + i);
+  sv = lp.likelihood != 0 ? (double)stream_load<BCHMC_NT_LIKE != 0>(noise + i) : 1.;
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256)
 k_partial_like(Geo g, LikePar lp, const T *__restrict__ rho, const double *__restrict__ rho_partials,
@@ -221,30 +254,10 @@ k_partial_like(Geo g, LikePar lp, const T *__restrict__ rho, const double *__res
   const double nmean = sum_partials(rho_partials, red) / (double)g.N;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < g.N;
        i += (long long)gridDim.x * blockDim.x) {
+    double w, nv, sv;
+    like_operands<T>(lp, i, nobs, noise, window, w, nv, sv);
     const double dX = (double)rho[i] / nmean - 1.;
-    const double w = stream_load<BCHMC_NT_LIKE != 0>(window + i);
-    double out = 0.;
-    if (lp.likelihood == 1) {
-      const double Lambda = w * lp.rho_c * pow_bias(1. + lp.biasP * dX, lp);
-      if ((w > 0.) && (Lambda > 0.0)) {
-        const double s = stream_load<BCHMC_NT_LIKE != 0>(noise + i);
-        out = ((double)stream_load<BCHMC_NT_LIKE != 0>(nobs + i) - Lambda) / (s * s);
-      }
-    } else if (lp.likelihood == 0) {
-      const double dens = 1. + lp.biasP * dX;
-      if ((w > 0.0) && (dens > 0.0)) {
-        const double Lambda = w * lp.rho_c * pow_bias(dens, lp);
-        const double dpow = lp.bias_is_identity ? 1. : pow(dens, lp.biasE - 1);
-        out = (1 - (double)nobs[i] / Lambda) * lp.rho_c * lp.biasE * lp.biasP * dpow;
-      }
-    } else {  // 2: log-normal
-      if (w > 0.) {
-        const double Lambda = log(lp.rho_c * pow_bias(1. + lp.biasP * dX, lp));
-        const double s = noise[i];
-        out = ((double)nobs[i] - Lambda) / (s * s);
-      }
-    }
-    plike[i] = (T)out;
+    plike[i] = (T)partial_like_value(lp, dX, w, nv, sv);
   }
 }
 

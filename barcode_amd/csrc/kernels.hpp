@@ -22,3 +22,4 @@
 #include "alpt.hpp"  // ALPT displacement (Lag2Eul_non_zeldovich)
 #include "spectrum.hpp"  // measure_spectrum
 #include "step_boundary_x.hpp"  // Planes mode: step boundary with the x passes of both transforms fused in
+#include "alpt_x.hpp"  // Planes mode of the ALPT displacement: mix + cell-boundary average with the x passes fused in

@@ -148,7 +148,11 @@ __device__ __forceinline__ void xfft_inplace(C2<T> *__restrict__ s, const C2<T> 
 //                p_out == nullptr: g^ only (k_assemble<false>), no trajectory control.
 enum { BX_INTERIOR = 0, BX_FIRST = 1, BX_LAST = 2 };
 
-template <typename T, int NT, int PER, int MODE = BX_INTERIOR>
+// ALPT = true changes what leaves through the two inverse x passes: instead of the Zel'dovich Psi^ (kx B and B, see
+// below) the two fields Lag2Eul_non_zeldovich starts from -- delta(1)^ = c_za q^' into component 0 and the Poisson
+// solution Phi^ = -delta(1)^ / k^2 (0 at k = 0; PoissonSolver, EqSolvers.cc:29-64: no Nyquist zeroing) into component 1
+// of Ck, with c_za = deltaQ_factor / N.  The ALPT model's own pipeline (alpt_x.hpp) takes over from there.
+template <typename T, int NT, int PER, int MODE = BX_INTERIOR, bool ALPT = false>
 __global__ void __launch_bounds__(NT, BCHMC_BX_WAVES)
 k_step_boundary_x(Geo g, int log2n, const C2<T> *__restrict__ twiddle, C2<T> *Ck, const C2<T> *q_in, const C2<T> *p_in,
                   C2<T> *q_out, C2<T> *p_out, const double *__restrict__ wS, const double *__restrict__ wM, double a,
@@ -308,7 +312,10 @@ k_step_boundary_x(Geo g, int log2n, const C2<T> *__restrict__ twiddle, C2<T> *Ck
     C2<T> o;
     o.x = T(0);
     o.y = T(0);
-    if (ksq > 1.e-14 && !nyq) {
+    if (ALPT) {
+      o.x = (T)(c_za * q.x);
+      o.y = (T)(c_za * q.y);
+    } else if (ksq > 1.e-14 && !nyq) {
       const double f = (1. / ksq) * kx;
       o.x = (T)(f * (c_za * q.y));
       o.y = (T)(f * -(c_za * q.x));
@@ -338,7 +345,11 @@ k_step_boundary_x(Geo g, int log2n, const C2<T> *__restrict__ twiddle, C2<T> *Ck
     C2<T> o;
     o.x = T(0);
     o.y = T(0);
-    if (ksq > 1.e-14 && !nyq) {
+    if (ALPT) {
+      const double f = (ksq > 0.) ? -1. / ksq : 0.;
+      o.x = (T)(f * (c_za * (double)qkeep[m].x));
+      o.y = (T)(f * (c_za * (double)qkeep[m].y));
+    } else if (ksq > 1.e-14 && !nyq) {
       const double2 qn = make_double2((double)qkeep[m].x, (double)qkeep[m].y);
       const double f = 1. / ksq;
       o.x = (T)(f * (c_za * qn.y));
@@ -351,6 +362,10 @@ k_step_boundary_x(Geo g, int log2n, const C2<T> *__restrict__ twiddle, C2<T> *Ck
   for (int m = 0; m < per; m++) {
     const int i = irow + rows * m;
     const C2<T> v = s[i * KB + c];
+    if (ALPT) {
+      bx_store(Ck + col + plane * i + g.Nhp, v);
+      continue;
+    }
     C2<T> oy, oz;
     oy.x = (T)(ky * (double)v.x);
     oy.y = (T)(ky * (double)v.y);

@@ -779,13 +779,19 @@ __host__ __device__ constexpr int hull81_zw(int a, int b) {
 #ifndef BCHMC_GATHER_WAVES
 #define BCHMC_GATHER_WAVES 5
 #endif
-template <typename T, int LY, int LZ, bool FIX>
+// STAGE: the work item does not add its LDS image to the global density with atomics but writes the whole image --
+// 12 x 12 x 20 doubles, halo included -- with plain coalesced stores to slot blockIdx.x of a staging area;
+// k_stage_combine81 below sums, per cell, the <= 8 images that cover it.  rho then needs no clearing, and the stores
+// overlap with the arithmetic of the other workgroups on the CU where the 2880 fp64 atomics per work item did not
+// (bound measured first, profiles/r03_ab_levers.txt: scatter 0.94 -> 0.81 ms per launch in the HIP-event profile).
+template <typename T, int LY, int LZ, bool FIX, bool STAGE = false>
 __global__ void __launch_bounds__(256, BCHMC_SCATTER_WAVES)
 k_scatter_tile81(Geo g, SphPar sp, TilePar tp, const RecQuad *__restrict__ srec,
                  const long long *__restrict__ off, const long long *__restrict__ tend, const int *__restrict__ woff,
                  const int4 *__restrict__ oct, const int *__restrict__ seg_in,
                  typename Cell<FIX, T>::type *__restrict__ rho, double *__restrict__ rho_part, int *__restrict__ cnt_zero,
-                 int ncnt_zero, double fix_scale) {
+                 int ncnt_zero, double fix_scale, double *__restrict__ stage = nullptr,
+                 const unsigned short *__restrict__ stage_inv = nullptr) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw_scatter81[];
   using Acc = typename Cell<FIX, double>::type;
   Acc *s_tile_acc = reinterpret_cast<Acc *>(s_raw_scatter81);
@@ -874,12 +880,24 @@ k_scatter_tile81(Geo g, SphPar sp, TilePar tp, const RecQuad *__restrict__ srec,
   }
   __syncthreads();
   double flushed = 0.;  // sum of everything this work item adds to rho: the mean density needs no pass over rho
-  for (int c = threadIdx.x; c < ncell; c += blockDim.x) {
-    const Acc v = s_tile_acc[c];
-    if (v != Acc(0)) {
-      const int cz = c % LZ, cy = (c / LZ) % LY, cx = c / (LZ * LY);
-      const int gx = (ox + cx + n) % n, gy = (oy + cy + n) % n, gz = (oz + cz + n) % n;
-      flushed += flush_cell(rho + gz + (long long)n * (gy + (long long)n * gx), v);
+  if (STAGE && !FIX) {
+    // staged image in OWNER-BLOCKED order: the cells that belong to each of the 27 tiles around (and including) this
+    // one are contiguous, so that the owner's combine pass reads whole runs (stage_inv: position -> LDS image cell)
+    double *st = stage + (size_t)blockIdx.x * (size_t)ncell;
+    const double *img = reinterpret_cast<const double *>(s_tile_acc);
+    for (int c = threadIdx.x; c < ncell; c += blockDim.x) {
+      const double v = img[stage_inv[c]];
+      st[c] = v;
+      flushed += v;
+    }
+  } else {
+    for (int c = threadIdx.x; c < ncell; c += blockDim.x) {
+      const Acc v = s_tile_acc[c];
+      if (v != Acc(0)) {
+        const int cz = c % LZ, cy = (c / LZ) % LY, cx = c / (LZ * LY);
+        const int gx = (ox + cx + n) % n, gy = (oy + cy + n) % n, gz = (oz + cz + n) % n;
+        flushed += flush_cell(rho + gz + (long long)n * (gy + (long long)n * gx), v);
+      }
     }
   }
   if (!FIX) {  // deterministic mode: k_fix_to_rho sums the converted field in a fixed order instead
@@ -889,6 +907,133 @@ k_scatter_tile81(Geo g, SphPar sp, TilePar tp, const RecQuad *__restrict__ srec,
   }
 }
 
+// Sum of the staged images (k_scatter_tile81<STAGE>) into rho.  Every cell of a 12 x 12 x 20 image belongs to exactly one
+// tile: the image's own tile (8 x 8 x 16 cells) or one of its 26 neighbours (the halo); the scatter stores an image
+// blocked by owner.  Seen from a tile, its 1024 cells receive 2880 staged cells per work item of the 27 tiles around
+// it -- the same 2880 (neighbour, staged position, own cell) triples for every tile, so they are a table (built once
+// on the host, ordered by staged position: a neighbour's contribution is ONE contiguous run, 8 KB from the tile's own
+// image down to 64 bytes from a corner neighbour, and consecutive threads read consecutive doubles).  One workgroup per tile: every thread owns
+// 12 table entries, issues its loads for all of them (one per work item of the neighbour: usually one) before it adds
+// anything -- the first version of this kernel walked the <= 8 images per cell in nested loops with one load in flight
+// per thread and took 0.46 ms at 256^3; this one is bound by the 0.4 + 0.4 GB it moves -- and accumulates in an LDS
+// image of the tile (ds_add_f64: up to 8 entries meet in a cell).
+// LIKE: overdens + the per-cell likelihood partial in the same pass (what k_partial_like does from rho), so the
+// density makes one trip; rho is still written (energies, fetch and the calc_h variants read it).
+constexpr int kStageCells = 12 * 12 * 20;
+constexpr int kStagePairs = kStageCells / 2;          // table entries: pairs of z-adjacent cells (16-byte loads)
+constexpr int kStagePer = (kStagePairs + 255) / 256;  // table entries per thread
+// entry: neighbour (0..26) | first own cell of the pair (0..1022, even) << 5 | staged position (0..2878, even) << 15
+__host__ __device__ constexpr unsigned stage_entry(int nb, int own, int pos) {
+  return (unsigned)nb | ((unsigned)own << 5) | ((unsigned)pos << 15);
+}
+
+// WRHO = false: the density itself is not stored (interior steps of a trajectory: only the likelihood partial is read).
+template <typename T, bool LIKE, bool WRHO>
+__global__ void __launch_bounds__(256)
+k_stage_combine81(Geo g, TilePar tp, LikePar lp, const double *__restrict__ stage, const unsigned *__restrict__ table,
+                  const int *__restrict__ woff, T *__restrict__ rho, const double *__restrict__ rho_partials,
+                  const T *__restrict__ nobs, const T *__restrict__ noise, const T *__restrict__ window,
+                  T *__restrict__ plike) {
+  __shared__ int s_first[2][32], s_cnt[2][32], s_maxcnt[2];
+  __shared__ __attribute__((aligned(16))) double acc[2][1024];
+  __shared__ double red[4];
+  double nmean = 1.;
+  if (LIKE) nmean = sum_partials(rho_partials, red) / (double)g.N;
+  unsigned ent[kStagePer];
+#pragma unroll
+  for (int m = 0; m < kStagePer; m++) {
+    const int e = (int)threadIdx.x + 256 * m;
+    ent[m] = e < kStagePairs ? table[e] : 0xffffffffu;
+  }
+  const int n = g.n, tid = (int)threadIdx.x;
+  // work items of the 27 tiles around `tile` (threads 0..26 of wave 0): first item and count, and the largest count
+  auto neighbours = [&](int tile, int &first, int &cnt) {
+    const int tzi = tile % tp.ntz, tyi = (tile / tp.ntz) % tp.nty, txi = tile / (tp.ntz * tp.nty);
+    const int dz = tid % 3 - 1, dy = (tid / 3) % 3 - 1, dx = tid / 9 - 1;
+    const int nx = (txi + dx + tp.ntx) % tp.ntx, ny = (tyi + dy + tp.nty) % tp.nty, nz = (tzi + dz + tp.ntz) % tp.ntz;
+    const int t = nz + tp.ntz * (ny + tp.nty * nx);
+    first = woff[t];
+    cnt = woff[t + 1] - first;
+  };
+  auto publish = [&](int buf, int first, int cnt) {  // wave 0 only
+    int mx = tid < 27 ? cnt : 0;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 32));
+    if (tid < 27) {
+      s_first[buf][tid] = first;
+      s_cnt[buf][tid] = cnt;
+    }
+    if (tid == 0) s_maxcnt[buf] = mx;
+  };
+#pragma unroll
+  for (int r = 0; r < 8; r++) (&acc[0][0])[tid + 256 * r] = 0.;
+  int tile = blockIdx.x, buf = 0;
+  if (tile < tp.ntiles && tid < 32) {
+    int f = 0, c = 0;
+    if (tid < 27) neighbours(tile, f, c);
+    publish(0, f, c);
+  }
+  __syncthreads();
+  // One barrier per tile: the accumulators are double-buffered and self-cleaning (a thread zeroes the four cells it has
+  // just read), and the neighbour lists of the NEXT tile are fetched while this one is summed.
+  // Consecutive tiles (z fastest) run on consecutive workgroups: the images a sweep touches are neighbours in memory.
+  for (; tile < tp.ntiles; tile += gridDim.x, buf ^= 1) {
+    const int next = tile + (int)gridDim.x;
+    int nf = 0, nc = 0;
+    if (next < tp.ntiles && tid < 27) neighbours(next, nf, nc);
+    const int tzi = tile % tp.ntz, tyi = (tile / tp.ntz) % tp.nty, txi = tile / (tp.ntz * tp.nty);
+    // the likelihood's data operands of this thread's four cells: requested now, used after the images are summed
+    double lw[4], ln[4], ls[4];
+    if (LIKE) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int c = tid + 256 * r;
+        const int z = c & 15, y = (c >> 4) & 7, x = c >> 7;
+        const long long i = (tzi * 16 + z) + (long long)n * ((tyi * 8 + y) + (long long)n * (txi * 8 + x));
+        like_operands<T>(lp, i, nobs, noise, window, lw[r], ln[r], ls[r]);
+      }
+    }
+    const int maxcnt = s_maxcnt[buf];
+    for (int w = 0; w < maxcnt; w++) {  // work items of a tile: one unless the tile holds more than `chunk` particles
+      double2 v[kStagePer];
+#pragma unroll
+      for (int m = 0; m < kStagePer; m++) {
+        const unsigned e = ent[m];
+        const int nb = (int)(e & 31u);
+        v[m] = make_double2(0., 0.);
+        if (e != 0xffffffffu && w < s_cnt[buf][nb])
+          v[m] = *reinterpret_cast<const double2 *>(stage + (size_t)(s_first[buf][nb] + w) * kStageCells + (e >> 15));
+      }
+#pragma unroll
+      for (int m = 0; m < kStagePer; m++) {
+        double *a = &acc[buf][(ent[m] >> 5) & 1023u];
+        if (v[m].x != 0.) unsafeAtomicAdd(a, v[m].x);
+        if (v[m].y != 0.) unsafeAtomicAdd(a + 1, v[m].y);
+      }
+    }
+    if (next < tp.ntiles && tid < 32) publish(buf ^ 1, nf, nc);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int c = tid + 256 * r;
+      const int z = c & 15, y = (c >> 4) & 7, x = c >> 7;
+      const long long i = (tzi * 16 + z) + (long long)n * ((tyi * 8 + y) + (long long)n * (txi * 8 + x));
+      const T d = (T)acc[buf][c];
+      acc[buf][c] = 0.;
+      if (WRHO) rho[i] = d;
+      if (LIKE) plike[i] = (T)partial_like_value(lp, (double)d / nmean - 1., lw[r], ln[r], ls[r]);
+    }
+  }
+}
+
+// Row stride of the gather's LDS image in cells: LZ + BCHMC_GATHER_LZPAD.  The lanes of a wave are DIFFERENT particles
+// in arbitrary home cells of the tile, so their ds_read_b64 addresses LZS (LY hx + hy) + hz are as good as random over
+// the 32 eight-byte banks whatever the stride: the 58 % bank-conflict share of the LDS-active cycles (r02 SQ counters)
+// is the birthday statistics of 16 random addresses per cycle on 32 banks, not a stride effect -- measured with pad 1
+// (profiles/r03_ab_levers.txt): no change.
+#ifndef BCHMC_GATHER_LZPAD
+#define BCHMC_GATHER_LZPAD 0
+#endif
 template <typename T, int LY, int LZ>
 __global__ void __launch_bounds__(256, BCHMC_GATHER_WAVES)
 k_gather_tile81(Geo g, HullPar hp, TilePar tp, int rsd, const RecQuad *__restrict__ srec,
@@ -902,6 +1047,7 @@ k_gather_tile81(Geo g, HullPar hp, TilePar tp, int rsd, const RecQuad *__restric
   OctMap om;
   if (!tile_work((int)blockIdx.x, tp, off, tend, woff, oct, seg_in, tile, rec0, pb, pe, om)) return;
   srec += rec0 * rec_quads<T>();  // this tile's record slots; pb, pe are relative to them
+  constexpr int LZS = LZ + BCHMC_GATHER_LZPAD;
   const int ncell = tp.lx * LY * LZ;
   const int n = g.n;
   const int tzi = tile % tp.ntz, tyi = (tile / tp.ntz) % tp.nty, txi = tile / (tp.ntz * tp.nty);
@@ -909,7 +1055,7 @@ k_gather_tile81(Geo g, HullPar hp, TilePar tp, int rsd, const RecQuad *__restric
   for (int c = threadIdx.x; c < ncell; c += blockDim.x) {
     const int cz = c % LZ, cy = (c / LZ) % LY, cx = c / (LZ * LY);
     const int gx = (ox + cx + n) % n, gy = (oy + cy + n) % n, gz = (oz + cz + n) % n;
-    s_tile_pl[c] = plike[gz + (long long)n * (gy + (long long)n * gx)];
+    s_tile_pl[cz + LZS * (cy + LY * cx)] = plike[gz + (long long)n * (gy + (long long)n * gx)];
   }
   __syncthreads();
   const T d_h = (T)hp.d_h, h_inv = (T)hp.h_inv, norm = (T)hp.norm;
@@ -949,7 +1095,7 @@ k_gather_tile81(Geo g, HullPar hp, TilePar tp, int rsd, const RecQuad *__restric
       }
 #endif
       const T c225n = T(2.25) * norm, c3n = T(-3) * norm, c34n = T(-0.75) * norm;
-      const T *corner = s_tile_pl + LZ * ((hy - 2) + LY * (hx - 2)) + (hz - 2);
+      const T *corner = s_tile_pl + LZS * ((hy - 2) + LY * (hx - 2)) + (hz - 2);
 #pragma unroll
       for (int a = 0; a < 5; a++) {
 #if BCHMC_GATHER_LEAN
@@ -968,7 +1114,7 @@ k_gather_tile81(Geo g, HullPar hp, TilePar tp, int rsd, const RecQuad *__restric
           const T r2ab = X_a + Y[b];
 #endif
           if (r2ab > T(4)) continue;
-          const T *row = corner + LZ * (b + LY * a);
+          const T *row = corner + LZS * (b + LY * a);
           // the column's part_like values first: their LDS latency hides behind the first candidate's arithmetic
           // (read where they are used, every candidate waited ~100 cycles on its own ds_read)
           T pl[5];

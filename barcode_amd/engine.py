@@ -66,7 +66,7 @@ _lib = None
 EXPORTS = ("bchmc_create", "bchmc_destroy", "bchmc_strerror", "bchmc_last_error", "bchmc_upload", "bchmc_fetch",
            "bchmc_leapfrog", "bchmc_leapfrog_dh", "bchmc_energies", "bchmc_delta_hamiltonian", "bchmc_gradient", "bchmc_forward",
            "bchmc_leapfrog_device", "bchmc_steps_done", "bchmc_energies_device", "bchmc_sync", "bchmc_stream",
-           "bchmc_profile", "bchmc_profile_read", "bchmc_kernel_name",
+           "bchmc_profile", "bchmc_profile_read", "bchmc_kernel_name", "bchmc_tile_info",
            "bchmc_chain_set_state", "bchmc_chain_get_state", "bchmc_chain_set_momenta", "bchmc_chain_get_momenta",
            "bchmc_chain_draw_momenta", "bchmc_chain_attempt", "bchmc_chain_get_proposal", "bchmc_chain_accept",
            "bchmc_measure_spectrum", "bchmc_philox_kat", "bchmc_kinetic_term", "bchmc_psi",
@@ -106,6 +106,7 @@ def load():
     lib.bchmc_sync.argtypes = [vp]
     lib.bchmc_stream.argtypes = [vp]
     lib.bchmc_stream.restype = vp
+    lib.bchmc_tile_info.argtypes = [vp, C.POINTER(C.c_int32)]
     lib.bchmc_profile.argtypes = [vp, C.c_int]
     lib.bchmc_profile_read.argtypes = [vp, dp, C.POINTER(u64)]
     lib.bchmc_kernel_name.argtypes = [C.c_int]
@@ -341,6 +342,12 @@ class Engine:
         sig = None if signal is None else _p(self._in(signal))
         self._chk(self.lib.bchmc_measure_spectrum(self.h, sig, int(n_bin), _p(kmode), _p(power)))
         return kmode, power
+
+    def tile_info(self):
+        out = (C.c_int32 * 8)()
+        self._chk(self.lib.bchmc_tile_info(self.h, out))
+        keys = ("tiled", "one_pass", "cap", "cap_alloc", "watch", "stage", "unrolled81", "alpt_planes")
+        return dict(zip(keys, [int(v) for v in out]))
 
     # ---- measurement ---------------------------------------------------------------------------
     def profile(self, enable):

@@ -196,6 +196,11 @@ int bchmc_chain_accept(bchmc_handle *h, int accepted);         /* accepted: q :=
 int bchmc_measure_spectrum(bchmc_handle *h, const double *signal, uint64_t n_bin, double *kmode, double *power);
 int bchmc_philox_kat(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]); /* known-answer hook for tests */
 
+/* Diagnostic (tests, logs): how the particle-mesh path is currently set up.  out = { tile-sorted path in use, one-pass
+ * binning in use, record slots per tile in use, record slots per tile allocated, long trajectories poll the slot words,
+ * staged density flush available, unrolled 81-cell kernels in use, ALPT planes pipeline available }. */
+int bchmc_tile_info(bchmc_handle *h, int32_t out[8]);
+
 /* ---- measurement hooks (bench.py): per-kernel-class HIP-event timing on the engine's stream ---- */
 enum {
   BCHMC_K_FFT_C2R = 0, BCHMC_K_FFT_R2C, BCHMC_K_KSPACE_DRIFT_ZA, BCHMC_K_SCATTER, BCHMC_K_MEAN_PARTIAL,

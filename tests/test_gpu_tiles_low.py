@@ -60,8 +60,10 @@ def test_calc_h3_interpolation_on_tiles_against_oracle():
         e = c.engine()
         g, _, _ = c.oracle.gradient_psi(c.q0)
         assert rel_l2(e.gradient(c.q0), g) < 10 * TOL_FIELD
-        for k in ("Vx", "Vy", "Vz"):
-            assert rel_l2(e.fetch(k), c.oracle.get(k)) < 10 * TOL_FIELD
+        pl = c.oracle.partial_f_delta_x_log_like(c.oracle.get("deltaX"))
+        V = c.oracle.likelihood_calc_V_SPH_fourier_TSC(pl, *[c.oracle.get(k) for k in ("posx", "posy", "posz")])
+        for k, ref in zip(("Vx", "Vy", "Vz"), V):
+            assert rel_l2(e.fetch(k), ref) < 10 * TOL_FIELD
         e.close()
 
 
