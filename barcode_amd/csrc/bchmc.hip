@@ -70,6 +70,7 @@ struct bchmc_handle {
   void *rho = nullptr, *plike = nullptr;             // N each
   long long *rho_fix = nullptr;                      // N: fixed-point density (deterministic mode only)
   int *fix_sat = nullptr;                            // 1: set by k_fix_to_rho when a fixed-point cell came near wrapping
+  long long fix_sat_limit = 1ll << 62;               // (BCHMC_FIX_SAT_LOG2 lowers it: test hook for the error path)
   bool fix = false;                                  // deterministic mode
   void *ioq = nullptr, *iop = nullptr;               // N each: staging / scratch
   void *gprior = nullptr, *glike = nullptr;          // N each, lazily allocated by bchmc_gradient
@@ -781,8 +782,32 @@ struct Pipe {
     }
     {
       ProfScope ps(h, BCHMC_K_OTHER);
-      k_alpt_grad<T><<<stencil_grid(h->g.n), 256, 0, h->stream>>>(h->g, phi, g3);
-      k_alpt_sources<T><<<stencil_grid(h->g.n), 256, 0, h->stream>>>(h->g, g3, d1, a_out, b_out, h->c.D1, h->c.D2);
+      const int n = h->g.n;
+      // row-staged stencils: RJ rows per workgroup, as many as fit 64 KB of LDS in the sources pass (7 RJ + 8 rows)
+      const int rj = (n % 32 == 0 && (size_t)36 * n * sizeof(T) <= 80 * 1024) ? 4
+                     : ((n % 16 == 0 && (size_t)22 * n * sizeof(T) <= 80 * 1024) ? 2 : 0);
+      if (rj && !env_on("BCHMC_NO_STENCIL_ROWS")) {
+        const int grid = std::min(n * (n / rj), 2048) / 8 * 8;
+        const size_t lds_g = (size_t)(5 * rj + 4) * n * sizeof(T), lds_s = (size_t)(7 * rj + 8) * n * sizeof(T);
+        if (rj == 4) {
+          auto kg = k_alpt_grad_rows<T, 4>;
+          auto ks = k_alpt_sources_rows<T, 4>;
+          HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kg), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_g));
+          HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
+          kg<<<grid, 256, lds_g, h->stream>>>(h->g, phi, g3);
+          ks<<<grid, 256, lds_s, h->stream>>>(h->g, g3, d1, a_out, b_out, h->c.D1, h->c.D2);
+        } else {
+          auto kg = k_alpt_grad_rows<T, 2>;
+          auto ks = k_alpt_sources_rows<T, 2>;
+          HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kg), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_g));
+          HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
+          kg<<<grid, 256, lds_g, h->stream>>>(h->g, phi, g3);
+          ks<<<grid, 256, lds_s, h->stream>>>(h->g, g3, d1, a_out, b_out, h->c.D1, h->c.D2);
+        }
+      } else {
+        k_alpt_grad<T><<<stencil_grid(n), 256, 0, h->stream>>>(h->g, phi, g3);
+        k_alpt_sources<T><<<stencil_grid(n), 256, 0, h->stream>>>(h->g, g3, d1, a_out, b_out, h->c.D1, h->c.D2);
+      }
       HIPCHK(hipGetLastError());
     }
     if (planes) {
@@ -979,7 +1004,7 @@ struct Pipe {
       HIPCHK(hipGetLastError());
       if (h->fix) {
         k_fix_to_rho<T><<<kRedBlocks, 256, 0, h->stream>>>(h->g.N, h->rho_fix, 1. / fix_scale, R(h->rho), h->rho_part,
-                                                           h->fix_sat);
+                                                           h->fix_sat, h->fix_sat_limit);
         HIPCHK(hipGetLastError());
       }
     }
@@ -1987,6 +2012,7 @@ int bchmc_create(const bchmc_config *cfg, bchmc_handle **out) {
     CHK(dev_alloc_bytes(h, &h->plike, N * e));
     if (h->fix) CHK(dev_alloc(h, &h->rho_fix, N));
     if (h->fix) CHK(dev_alloc(h, &h->fix_sat, (size_t)1));
+    if (const char *ev = std::getenv("BCHMC_FIX_SAT_LOG2")) h->fix_sat_limit = 1ll << std::min(std::max(atoi(ev), 1), 62);
     CHK(dev_alloc_bytes(h, &h->ioq, N * e));
     CHK(dev_alloc_bytes(h, &h->iop, N * e));
     CHK(dev_alloc(h, &h->dstage, 2 * N));

@@ -170,7 +170,7 @@ __global__ void __launch_bounds__(256) k_sum(const T *__restrict__ a, long long 
 template <typename T>
 __global__ void __launch_bounds__(256)
 k_fix_to_rho(long long N, const long long *__restrict__ fix, double inv_scale, T *__restrict__ rho,
-             double *__restrict__ partials, int *__restrict__ saturated) {
+             double *__restrict__ partials, int *__restrict__ saturated, long long sat_limit) {
   __shared__ double red[4];
   double acc = 0.;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < N; i += (long long)gridDim.x * blockDim.x) {
@@ -178,7 +178,7 @@ k_fix_to_rho(long long N, const long long *__restrict__ fix, double inv_scale, T
     // every contribution is >= 0, so a negative cell has wrapped, and one beyond 2^62 (2^16 maximal contributions) is
     // within a factor two of doing so: the host turns the flag into BCHMC_ERR_STATE at its next read-back instead of
     // handing out a plausible-looking density
-    if (f > (1ll << 62) || f < 0) *saturated = 1;  // benign race: every writer stores 1
+    if (f > sat_limit || f < 0) *saturated = 1;  // sat_limit = 2^62; benign race: every writer stores 1
     const T v = (T)((double)f * inv_scale);
     rho[i] = v;
     acc += (double)v;

@@ -776,6 +776,9 @@ __host__ __device__ constexpr int hull81_zw(int a, int b) {
 #ifndef BCHMC_GATHER_LEAN
 #define BCHMC_GATHER_LEAN 1
 #endif
+#ifndef BCHMC_SCATTER_NOCLAMP
+#define BCHMC_SCATTER_NOCLAMP 0
+#endif
 #ifndef BCHMC_GATHER_WAVES
 #define BCHMC_GATHER_WAVES 5
 #endif
@@ -868,7 +871,15 @@ k_scatter_tile81(Geo g, SphPar sp, TilePar tp, const RecQuad *__restrict__ srec,
             if (home) {
               val = r_fma(q2, r_fma(c34w, q, c32w), w_norm);
             } else {
+#if BCHMC_SCATTER_NOCLAMP
+              // no clamp at q = 2: a q that the test above admitted a hair beyond 2 (q2_lim = 4 (1 + 1e-12)) deposits
+              // -(q - 2)^3 w / 4 >= -1e-37 w instead of exactly 0 -- below the resolution of every sum it enters, and
+              // where it is the only contribution to a cell, a negative density takes the same `Lambda > 0` / `dens > 0`
+              // branch of the likelihood partial as the reference's 0 (forward_model.hpp: partial_like_value)
+              const T t = T(2) - q;
+#else
               const T t = r_max(T(2) - q, T(0));
+#endif
               const T outer = (c14w * t) * (t * t);
               val = far ? outer : ((q2 <= T(1)) ? r_fma(q2, r_fma(c34w, q, c32w), w_norm) : outer);
             }
@@ -1034,6 +1045,9 @@ k_stage_combine81(Geo g, TilePar tp, LikePar lp, const double *__restrict__ stag
 #ifndef BCHMC_GATHER_LZPAD
 #define BCHMC_GATHER_LZPAD 0
 #endif
+#ifndef BCHMC_GATHER_EXPANDED
+#define BCHMC_GATHER_EXPANDED 1
+#endif
 template <typename T, int LY, int LZ>
 __global__ void __launch_bounds__(256, BCHMC_GATHER_WAVES)
 k_gather_tile81(Geo g, HullPar hp, TilePar tp, int rsd, const RecQuad *__restrict__ srec,
@@ -1095,6 +1109,9 @@ k_gather_tile81(Geo g, HullPar hp, TilePar tp, int rsd, const RecQuad *__restric
       }
 #endif
       const T c225n = T(2.25) * norm, c3n = T(-3) * norm, c34n = T(-0.75) * norm;
+#if BCHMC_GATHER_EXPANDED
+      const T c3p = T(3) * norm;  // -4 c34n; 4 c34n is c3n
+#endif
       const T *corner = s_tile_pl + LZS * ((hy - 2) + LY * (hx - 2)) + (hz - 2);
 #pragma unroll
       for (int a = 0; a < 5; a++) {
@@ -1141,8 +1158,15 @@ k_gather_tile81(Geo g, HullPar hp, TilePar tp, int rsd, const RecQuad *__restric
               if (home) {
                 gr = r_fma(c225n, q, c3n);
               } else {
+#if BCHMC_GATHER_EXPANDED
+                // -3/4 (q - 2)^2 / q = -3/4 (q - 4 + 4 / q): two fused multiply-adds from q and 1/q instead of a
+                // subtraction and three multiplications.  Cancels near q = 2, where the term itself vanishes: the
+                // absolute error stays at a few 1e-16 of the O(1) terms it is summed with.
+                const T outer = r_fma(c3n, rq, r_fma(c34n, q, c3p));
+#else
                 const T qm2 = q - T(2);
                 const T outer = ((qm2 * qm2) * c34n) * rq;
+#endif
                 gr = far ? outer : ((q_sq > T(1)) ? outer : r_fma(c225n, q, c3n));
               }
               const T common = pl[c] * gr;

@@ -42,9 +42,9 @@ def parse():
     ap.add_argument("--mk", type=int, default=3, help="masskernel 0 NGP / 1 CIC / 2 TSC / 3 SPH (default; anything else is a "
                                                       "separate line, never the headline)")
     ap.add_argument("--calc-h", type=int, default=2, help="likelihood-force variant 0..3 (default 2; mk != 3 needs 0 or 1)")
-    ap.add_argument("--sustained", type=float, default=0.0,
-                    help="additionally run ONE trajectory long enough for about this many seconds (>= 3 to be called "
-                         "sustained) and report it as `sustained` next to the headline")
+    ap.add_argument("--sustained", type=float, default=3.0,
+                    help="N = 1: additionally run ONE trajectory long enough for about this many seconds and report it as "
+                         "`sustained` next to the headline (untimed part of the run; 0 switches it off)")
     ap.add_argument("--no-rccl-probe", action="store_true",
                     help="N > 1 on nccl: skip the untimed ncclAllGather through the library's own RCCL transport")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -8,7 +8,7 @@ mkdir -p gpurun_out
 for r in $(seq 1 $rounds); do
   for cfg in "$@"; do
     envs=$cfg; [ "$cfg" = "-" ] && envs=""
-    env $envs timeout -k 10 300 python bench.py --steps 40 --warmup 4 --no-cpu-baseline $args 2>gpurun_out/ab_env.err > gpurun_out/ab_env.json || { echo "FAILED: $cfg"; tail -3 gpurun_out/ab_env.err; exit 1; }
+    env $envs timeout -k 10 300 python bench.py --steps 40 --warmup 4 --no-cpu-baseline --sustained 0 $args 2>gpurun_out/ab_env.err > gpurun_out/ab_env.json || { echo "FAILED: $cfg"; tail -3 gpurun_out/ab_env.err; exit 1; }
     python - "$cfg" gpurun_out/ab_env.json <<'PY'
 import json, sys
 d = json.load(open(sys.argv[2]))

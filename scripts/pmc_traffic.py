@@ -34,13 +34,13 @@ def load(path, counter):
     # first step: k_kick_drift_za<true>, or -- planes mode at the ends -- the SECOND BX_FIRST launch of
     # k_step_boundary_x after k_init_ctl (the first one is the Psi^ of the force evaluation before the first step)
     drift = re.compile(r"k_kick_drift_za<(double, |float, )?true>")
-    bx_first = re.compile(r"k_step_boundary_x<.*, 1>")
+    bx_first = re.compile(r"k_step_boundary_x<.*, 1(, (false|true))?>")
     cand = [i for i in range(start, len(names)) if bx_first.fullmatch(names[i])]
     if len(cand) >= 2:
         first = cand[1]
     else:
         first = next(i for i in range(start, len(names)) if drift.fullmatch(names[i]))
-    end = re.compile(r"k_step_boundary<.*>|k_step_boundary_x<.*, 2>|k_assemble<(double, |float, )?true>")
+    end = re.compile(r"k_step_boundary<.*>|k_step_boundary_x<.*, 2(, (false|true))?>|k_assemble<(double, |float, )?true>")
     last = max(i for i, n in enumerate(names) if end.fullmatch(n))
     per = defaultdict(lambda: [0.0, 0])
     for r, n in zip(rows[first:last + 1], names[first:last + 1]):

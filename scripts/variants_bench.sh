@@ -4,7 +4,7 @@
 tag=${1:-r03}; out=gpurun_out; mkdir -p $out
 export TMPDIR=/tmp
 line() {  # name, env, bench args
-  env $2 timeout -k 10 400 python3 bench.py --steps 40 --warmup 4 --no-cpu-baseline $3 2>$out/vb.err > $out/vb.json || { echo "FAILED $1"; tail -3 $out/vb.err; return; }
+  env $2 timeout -k 10 400 python3 bench.py --steps 40 --warmup 4 --no-cpu-baseline --sustained 0 $3 2>$out/vb.err > $out/vb.json || { echo "FAILED $1"; tail -3 $out/vb.err; return; }
   python3 - "$1" $out/vb.json <<'PY'
 import json, sys
 d = json.load(open(sys.argv[2]))
@@ -15,7 +15,7 @@ PY
   cp $out/vb.json $out/${tag}_bench_$1.json
 }
 stats() {  # name, bench args
-  rocprofv3 --kernel-trace --stats -d $out/vb_stats -o st --output-format csv -- python3 bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-kernel-profile $2 > $out/vb_stats.log 2>&1
+  rocprofv3 --kernel-trace --stats -d $out/vb_stats -o st --output-format csv -- python3 bench.py --steps 20 --warmup 2 --no-cpu-baseline --sustained 0 --no-kernel-profile $2 > $out/vb_stats.log 2>&1
   cp $(find $out/vb_stats -name '*kernel_stats.csv' | head -1) $out/${tag}_kernel_stats_$1.csv && rm -rf $out/vb_stats
 }
 {

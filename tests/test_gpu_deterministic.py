@@ -105,3 +105,24 @@ def test_carried_gradient_is_the_recomputed_one_bit_for_bit(monkeypatch):
     for (dH_a, t_a, q_a, p_a), (dH_b, t_b, q_b, p_b) in zip(*outs):
         assert dH_a == dH_b and np.array_equal(t_a, t_b)
         assert np.array_equal(q_a, q_b) and np.array_equal(p_a, p_b)
+
+
+def test_fixed_point_saturation_is_reported_not_hidden(monkeypatch):
+    """a fixed-point density cell that came within a factor two of wrapping (or came out negative) must turn
+    into BCHMC_ERR_STATE at the next synchronising call, not into a plausible density.  The limit is 2^62 (2^16 maximal
+    contributions per cell); the test hook lowers it to 2^47 -- two maximal contributions -- so that an ordinary field
+    trips it."""
+    from barcode_amd.engine import BchmcError, Engine
+    c = Case(Nx=16, likelihood=1, rsd_model=1)
+    monkeypatch.setenv("BCHMC_FIX_SAT_LOG2", "47")
+    e = Engine(c.p, deterministic=1)
+    e.upload(**c.arrays())
+    with pytest.raises(BchmcError) as err:
+        e.forward(c.truth, 1)
+    assert err.value.code == 9 and "fixed-point range" in str(err.value)
+    e.close()
+    monkeypatch.delenv("BCHMC_FIX_SAT_LOG2")
+    e = Engine(c.p, deterministic=1)                       # the real limit: an ordinary field is far below it
+    e.upload(**c.arrays())
+    e.forward(c.truth, 1)
+    e.close()
