@@ -51,7 +51,10 @@ __device__ __forceinline__ double findif_axis(const T *__restrict__ a, long long
 // consecutive rows on consecutive workgroups every XCD fetched every row of the array for its y neighbours.  Here the
 // row slots a workgroup takes (b, b + gridDim, ...; gridDim a multiple of 8) all lie in ONE slab of n / 8 consecutive j
 // -- the same slab for all workgroups of an XCD -- so the y and x neighbours of a row are rows of the same XCD, but for
-// the two rows at each slab edge.  Pure scheduling: any mapping gives the same numbers.
+// the two rows at each slab edge.  Pure scheduling: any mapping gives the same numbers.  (Measured: the two passes
+// 0.70 -> 0.61 ms at 256^3.  Staging the rows of a group of 4 output rows in LDS instead -- 6 and 9 coalesced row loads
+// per output row, neighbours read from LDS -- was measured too and ran 1.10 ms: 72 KB of LDS per workgroup leave two
+// workgroups per CU and nothing to overlap their load phases with; profiles/r03_ab_alpt_rows.txt.)
 __device__ __forceinline__ void stencil_row(int slot, int n, int &i, int &j) {
   if ((n & 7) == 0) {
     const int slab = n >> 3, x = slot & 7, loc = slot >> 3;
@@ -112,131 +115,6 @@ k_alpt_sources(Geo g, const T *__restrict__ g3, const T *d1, T *a_out, T *b_out,
     else
       psisc = -3.;
     b_out[p] = (T)(-psisc);
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------------
-// Row-staged forms of the two stencil passes (n a multiple of 8 RJ: otherwise the kernels above run).
-// The passes above issue 13 / 25 global loads per cell, nearly all of them L1 / L2 hits on neighbours another thread
-// also loads; here a workgroup takes RJ consecutive z-rows (j0 .. j0 + RJ - 1 at one i), stages every row its stencils
-// touch in LDS with coalesced row loads -- the RJ + 4 rows j0 - 2 .. j0 + RJ + 1 of plane i and the RJ rows of each of
-// the planes i - 2, i - 1, i + 1, i + 2 -- and reads the neighbours from there: 6 (grad) and 9 (sources) row loads
-// per output row instead of 13 and 25.  Same expressions in the same order as findif_axis: same numbers.
-// Workgroup -> row group is XCD-aware like stencil_row: the groups of one XCD lie in one slab of j.
-// ------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double findif5(double ll, double l, double r, double rr, double fac) {
-  return -(fac * ((4.0 / 3) * (l - r) - (1.0 / 6) * (ll - rr)));
-}
-__device__ __forceinline__ void stencil_group(int slot, int n, int ngroups, int &i, int &jg) {
-  if ((ngroups & 7) == 0) {
-    const int slab = ngroups >> 3, x = slot & 7, loc = slot >> 3;
-    jg = x * slab + loc % slab;
-    i = loc / slab;
-  } else {
-    jg = slot % ngroups;
-    i = slot / ngroups;
-  }
-}
-__device__ __forceinline__ int wrapn(int c, int n) { return c < 0 ? c + n : (c >= n ? c - n : c); }
-
-// LDS row index helpers for a field staged around (i, j0 .. j0 + RJ - 1):
-//   plane i:            rows j0 - 2 .. j0 + RJ + 1  -> slots 0 .. RJ + 3   (row j0 + jr is slot jr + 2)
-//   planes i + d, d = -2, -1, 1, 2 (index p = 0..3): rows j0 .. j0 + RJ - 1 -> slots RJ + 4 + p RJ + jr
-template <typename T, int RJ>
-__device__ __forceinline__ void stage_cross(const T *__restrict__ a, T *__restrict__ s, int n, int i, int j0) {
-  const long long nn = n;
-  for (int r = 0; r < RJ + 4; r++) {
-    const T *row = a + nn * (wrapn(j0 - 2 + r, n) + nn * i);
-    for (int k = threadIdx.x; k < n; k += blockDim.x) s[r * n + k] = row[k];
-  }
-#pragma unroll
-  for (int p = 0; p < 4; p++) {
-    const int ip = wrapn(i + (p < 2 ? p - 2 : p - 1), n);
-    for (int jr = 0; jr < RJ; jr++) {
-      const T *row = a + nn * (wrapn(j0 + jr, n) + nn * ip);
-      for (int k = threadIdx.x; k < n; k += blockDim.x) s[(RJ + 4 + p * RJ + jr) * n + k] = row[k];
-    }
-  }
-}
-
-template <typename T, int RJ>
-__global__ void __launch_bounds__(256) k_alpt_grad_rows(Geo g, const T *__restrict__ phi, T *__restrict__ g3) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw_grad[];
-  T *s = reinterpret_cast<T *>(s_raw_grad);
-  const int n = g.n, ngroups = n / RJ;
-  const double fac = g.n / (2. * g.L);
-  const long long nn = n;
-  for (int slot = blockIdx.x; slot < n * ngroups; slot += gridDim.x) {
-    int i, jg;
-    stencil_group(slot, n, ngroups, i, jg);
-    const int j0 = jg * RJ;
-    __syncthreads();
-    stage_cross<T, RJ>(phi, s, n, i, j0);
-    __syncthreads();
-    for (int jr = 0; jr < RJ; jr++) {
-      const T *c = s + (jr + 2) * n;  // row j0 + jr of plane i
-      for (int k = threadIdx.x; k < n; k += blockDim.x) {
-        const long long p = k + nn * ((j0 + jr) + nn * i);
-        auto pl = [&](int q) { return (double)s[(RJ + 4 + q * RJ + jr) * n + k]; };  // planes i-2, i-1, i+1, i+2
-        g3[p] = (T)findif5(pl(0), pl(1), pl(2), pl(3), fac);
-        g3[p + g.N] = (T)findif5((double)c[k - 2 * n], (double)c[k - n], (double)c[k + n], (double)c[k + 2 * n], fac);
-        g3[p + 2 * g.N] = (T)findif5((double)c[wrapn(k - 2, n)], (double)c[wrapn(k - 1, n)], (double)c[wrapn(k + 1, n)],
-                                     (double)c[wrapn(k + 2, n)], fac);
-      }
-    }
-  }
-}
-
-template <typename T, int RJ>
-__global__ void __launch_bounds__(256)
-k_alpt_sources_rows(Geo g, const T *__restrict__ g3, const T *d1, T *a_out, T *b_out, double D1, double D2) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw_src[];
-  T *sx = reinterpret_cast<T *>(s_raw_src);  // gx: cross (5 RJ + 4 rows)
-  const int n = g.n, ngroups = n / RJ;
-  T *sy = sx + (size_t)(5 * RJ + 4) * n;     // gy: plane i, rows j0 - 2 .. j0 + RJ + 1
-  T *sz = sy + (size_t)(RJ + 4) * n;         // gz: plane i, rows j0 .. j0 + RJ - 1
-  const double fac = g.n / (2. * g.L);
-  const long long nn = n;
-  const T *gx = g3, *gy = g3 + g.N, *gz = g3 + 2 * g.N;
-  for (int slot = blockIdx.x; slot < n * ngroups; slot += gridDim.x) {
-    int i, jg;
-    stencil_group(slot, n, ngroups, i, jg);
-    const int j0 = jg * RJ;
-    __syncthreads();
-    stage_cross<T, RJ>(gx, sx, n, i, j0);
-    for (int r = 0; r < RJ + 4; r++) {
-      const T *row = gy + nn * (wrapn(j0 - 2 + r, n) + nn * i);
-      for (int k = threadIdx.x; k < n; k += blockDim.x) sy[r * n + k] = row[k];
-    }
-    for (int jr = 0; jr < RJ; jr++) {
-      const T *row = gz + nn * ((j0 + jr) + nn * i);
-      for (int k = threadIdx.x; k < n; k += blockDim.x) sz[jr * n + k] = row[k];
-    }
-    __syncthreads();
-    for (int jr = 0; jr < RJ; jr++) {
-      const T *cx = sx + (jr + 2) * n, *cy = sy + (jr + 2) * n, *cz = sz + jr * n;
-      for (int k = threadIdx.x; k < n; k += blockDim.x) {
-        const long long p = k + nn * ((j0 + jr) + nn * i);
-        const int k2m = wrapn(k - 2, n), k1m = wrapn(k - 1, n), k1p = wrapn(k + 1, n), k2p = wrapn(k + 2, n);
-        auto px = [&](int q) { return (double)sx[(RJ + 4 + q * RJ + jr) * n + k]; };
-        const double xx = findif5(px(0), px(1), px(2), px(3), fac);
-        const double xy = findif5((double)cx[k - 2 * n], (double)cx[k - n], (double)cx[k + n], (double)cx[k + 2 * n], fac);
-        const double xz = findif5((double)cx[k2m], (double)cx[k1m], (double)cx[k1p], (double)cx[k2p], fac);
-        const double yy = findif5((double)cy[k - 2 * n], (double)cy[k - n], (double)cy[k + n], (double)cy[k + 2 * n], fac);
-        const double yz = findif5((double)cy[k2m], (double)cy[k1m], (double)cy[k1p], (double)cy[k2p], fac);
-        const double zz = findif5((double)cz[k2m], (double)cz[k1m], (double)cz[k1p], (double)cz[k2p], fac);
-        const double m2v = xx * yy - xy * xy + xx * zz - xz * xz + yy * zz - yz * yz;
-        const double dl = (double)d1[p];
-        a_out[p] = (T)(D1 * dl - D2 * m2v);
-        const double psilin = -D1 * dl;
-        double psisc;
-        if (1. + 2. / 3. * psilin > 0.)
-          psisc = 3. * (sqrt(1. + 2. / 3. * psilin) - 1.);
-        else
-          psisc = -3.;
-        b_out[p] = (T)(-psisc);
-      }
     }
   }
 }

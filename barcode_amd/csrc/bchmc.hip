@@ -374,16 +374,18 @@ int check_inputs(bchmc_handle *h) {
   return BCHMC_OK;
 }
 
-// One-pass tile binning, sizing of the record slots.  Every (tile, octant) owns tp.cap / 8 slots inside an array that was
-// allocated for cap_alloc slots per tile (16x the mean occupancy to start with); k_scan_tiles leaves the largest
-// (tile, octant) population of each binning in a device word, k_bin_direct stamps a sticky flag with the segment size
-// when a segment was too small (that force evaluation then ran the exact two-pass sort).  The host reads both words
-// wherever it synchronises anyway (read_ctl: bchmc_steps_done, bchmc_sync, bchmc_forward, the end of a chain attempt)
-// and -- for trajectories on a field whose populations are close to the segment size -- every few steps through a
-// lagging snapshot (poll_slots), and re-partitions the SAME allocation: segments of 1.5x the largest population seen,
-// up when one overflowed or is nearly full, down when that is less than 60 % of the current size (denser records are
-// cheaper to stream).  No reallocation, hence no cost, unless 1.5x the population exceeds the allocation itself; that
-// happens only at a synchronising call.  VERDICT r2 items 2(ii) and 7.
+// One-pass tile binning, sizing of the record slots.  Every (tile, octant) owns tp.cap / 8 slots of an array allocated for
+// cap_alloc slots per tile (16x the mean occupancy to start with); k_scan_tiles leaves the largest (tile, octant)
+// population of each binning in a device word, k_bin_direct stamps a sticky flag with the segment size when a segment
+// was too small (that force evaluation then ran the exact two-pass sort).  The host reads both words wherever it
+// synchronises anyway (read_ctl: bchmc_steps_done, bchmc_sync, bchmc_forward, the end of a chain attempt).  When a
+// segment overflowed or is more than 7/8 full, the partition grows to the WHOLE allocation, and if 1.5x the largest
+// population does not fit that either, the array is reallocated for it (+25 %) -- sized from what was measured, not
+// doubled blindly (VERDICT r2 items 2 ii and 7).  It never shrinks: denser slots were measured to buy 0.01 ms per
+// binning (profiles/r03_ab_slots.txt), and a partition fitted to a quiet start field overflowed in the middle of a
+// 1100-step trajectory whose populations doubled on the way (profiles/r03_sustained_ab.txt: 311 against 336 steps/s).
+// A partition smaller than the allocation (BCHMC_SORT_CAP) is also extended inside a trajectory, by a lagging poll
+// every few steps (poll_slots).
 int *slot_words(bchmc_handle *h) { return h->t_cnt + (kOct + 1) * (size_t)h->tp.ntiles + 1; }  // {sticky stamp, max}
 
 int realloc_slots(bchmc_handle *h, long long cap) {
@@ -416,26 +418,25 @@ int adapt_slots(bchmc_handle *h, int sticky, int maxc, bool may_realloc) {
   const long long seg = h->tp.cap / kOct;
   const bool ovf = sticky != 0 && sticky >= seg;  // a smaller stamp predates the last re-partitioning
   if (maxc <= 0 && !ovf) return BCHMC_OK;
-  long long want = ((3ll * maxc) / 2 + 16 + 7) / 8 * 8;
-  if (ovf && want <= seg) want = 2 * seg;          // no population figure (cannot happen with k_scan_tiles): double
-  long long nseg = seg;
-  if (ovf || 8ll * maxc > 7 * seg) nseg = std::max(want, seg + 8);
-  else if (5 * want < 3 * seg) nseg = want;
-  h->slot_watch = ovf || 4ll * maxc > 3 * nseg;    // within 25 % of the limit: keep an eye on long trajectories
-  if (nseg == seg) return BCHMC_OK;
-  long long ncap = nseg * kOct;
-  if (ncap > h->cap_alloc) {
+  const long long whole = h->cap_alloc - h->cap_alloc % kOct;
+  h->slot_watch = h->tp.cap < whole && (ovf || 4ll * maxc > 3 * seg);  // room left to extend into: keep an eye on it
+  if (!ovf && 8ll * maxc <= 7 * seg) return BCHMC_OK;
+  long long want = ((3ll * maxc) / 2 + 16 + 7) / 8 * 8;  // segments of 1.5x the largest population
+  if (want <= seg) want = 2 * seg;                        // overflow without a population figure: double
+  long long ncap = std::max(want * kOct, whole);          // at least everything that is allocated
+  if (ncap > whole) {
     if (may_realloc) {
       CHK(realloc_slots(h, ncap + ncap / 4));
       if (!h->sort_direct) return BCHMC_OK;
       h->cap_wanted = 0;
+      ncap = h->cap_alloc - h->cap_alloc % kOct;
     } else {
       h->cap_wanted = ncap;  // the next synchronising call reallocates; until then the largest partition that fits
-      ncap = h->cap_alloc - h->cap_alloc % kOct;
-      h->slot_watch = false; // nothing more to gain from polling: every step until then runs the two-pass sort
-      if (ncap == h->tp.cap) return BCHMC_OK;
+      ncap = whole;
     }
   }
+  h->slot_watch = false;     // nothing left to extend into
+  if (ncap == h->tp.cap) return BCHMC_OK;
   if (env_on("BCHMC_VERBOSE"))
     fprintf(stderr, "bchmc: record slots per tile %d -> %lld (largest (tile, octant) population %d%s)\n", h->tp.cap, ncap,
             maxc, ovf ? ", a segment overflowed" : "");
@@ -782,32 +783,8 @@ struct Pipe {
     }
     {
       ProfScope ps(h, BCHMC_K_OTHER);
-      const int n = h->g.n;
-      // row-staged stencils: RJ rows per workgroup, as many as fit 64 KB of LDS in the sources pass (7 RJ + 8 rows)
-      const int rj = (n % 32 == 0 && (size_t)36 * n * sizeof(T) <= 80 * 1024) ? 4
-                     : ((n % 16 == 0 && (size_t)22 * n * sizeof(T) <= 80 * 1024) ? 2 : 0);
-      if (rj && !env_on("BCHMC_NO_STENCIL_ROWS")) {
-        const int grid = std::min(n * (n / rj), 2048) / 8 * 8;
-        const size_t lds_g = (size_t)(5 * rj + 4) * n * sizeof(T), lds_s = (size_t)(7 * rj + 8) * n * sizeof(T);
-        if (rj == 4) {
-          auto kg = k_alpt_grad_rows<T, 4>;
-          auto ks = k_alpt_sources_rows<T, 4>;
-          HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kg), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_g));
-          HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
-          kg<<<grid, 256, lds_g, h->stream>>>(h->g, phi, g3);
-          ks<<<grid, 256, lds_s, h->stream>>>(h->g, g3, d1, a_out, b_out, h->c.D1, h->c.D2);
-        } else {
-          auto kg = k_alpt_grad_rows<T, 2>;
-          auto ks = k_alpt_sources_rows<T, 2>;
-          HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kg), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_g));
-          HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
-          kg<<<grid, 256, lds_g, h->stream>>>(h->g, phi, g3);
-          ks<<<grid, 256, lds_s, h->stream>>>(h->g, g3, d1, a_out, b_out, h->c.D1, h->c.D2);
-        }
-      } else {
-        k_alpt_grad<T><<<stencil_grid(n), 256, 0, h->stream>>>(h->g, phi, g3);
-        k_alpt_sources<T><<<stencil_grid(n), 256, 0, h->stream>>>(h->g, g3, d1, a_out, b_out, h->c.D1, h->c.D2);
-      }
+      k_alpt_grad<T><<<stencil_grid(h->g.n), 256, 0, h->stream>>>(h->g, phi, g3);
+      k_alpt_sources<T><<<stencil_grid(h->g.n), 256, 0, h->stream>>>(h->g, g3, d1, a_out, b_out, h->c.D1, h->c.D2);
       HIPCHK(hipGetLastError());
     }
     if (planes) {
@@ -1423,7 +1400,8 @@ struct Pipe {
     }
     for (uint64_t s = 0; s < neps; s++) {
       const bool last = (s + 1 == neps);
-      if (h->slot_watch && h->tiled && h->sort_direct && s > 0 && s % kSlotPoll == 0) CHK(poll_slots(h, s / kSlotPoll));
+      if (h->slot_watch && h->tiled && h->sort_direct && s > 0 && s % kSlotPoll == 0 && !env_on("BCHMC_NO_SLOT_POLL"))
+        CHK(poll_slots(h, s / kSlotPoll));
       h->planes_c2r = planes && (s > 0 || ends);  // Psi^ left by k_step_boundary_x still needs only the (y, z) passes
       h->planes_r2c = planes && (!last || ends);  // ... and V^ for it gets only those
       h->alpt_pending = alpt_x;                    // ... or delta(1)^ | Phi^ planes for the ALPT pipeline
@@ -2087,9 +2065,9 @@ int bchmc_create(const bchmc_config *cfg, bchmc_handle **out) {
           if (cfg->particle_kernel_h < 0.8661 * g.d) is81 = false;
           h->std81 = is81 && cfg->mk == 3 && !env_on("BCHMC_NO_UNROLL");
           // One-pass binning: the record array holds cap_alloc = 16x the mean occupancy in slots per tile (the 288 GB
-          // of HBM pay for a whole pass over the particles: 8.6 GB at 256^3 fp64), of which tp.cap -- eight octant
-          // segments of cap / 8 -- are in use: 8x the mean to start with, then 1.5x the largest (tile, octant) population
-          // the binning reports (adapt_slots).  BCHMC_SORT_CAP overrides the starting partition (a tiny value forces
+          // of HBM pay for a whole pass over the particles: 8.6 GB at 256^3 fp64), all of it in use as eight octant
+          // segments of cap / 8; it is reallocated for 1.5x the largest (tile, octant) population the binning reports
+          // when that does not fit (adapt_slots).  BCHMC_SORT_CAP overrides the starting partition (a tiny value forces
           // the two-pass fallback in tests; 0 disables the one-pass path), BCHMC_SORT_CAP_FIXED=1 keeps it for good.
           const long long mean_occ = (long long)tp.tx * tp.ty * tp.tz;
           long long cap = std::max<long long>(8 * mean_occ, 64);
@@ -2099,9 +2077,11 @@ int bchmc_create(const bchmc_config *cfg, bchmc_handle **out) {
           size_t nrec = N;
           h->sort_direct = cap > 0 && cap < (1ll << 30);  // record offsets are 64-bit, per-tile ranges 32-bit
           if (h->sort_direct) {
-            tp.cap = (int)cap;
             h->cap_alloc = h->cap_pinned ? cap : std::max<long long>(cap, std::max<long long>(16 * mean_occ, 128));
+            // the whole allocation is in use unless BCHMC_SORT_CAP asked for a smaller start (tests of the growth paths)
+            tp.cap = (int)(std::getenv("BCHMC_SORT_CAP") ? cap : h->cap_alloc - h->cap_alloc % kOct);
             nrec = std::max<size_t>(N, (size_t)h->cap_alloc * tp.ntiles);
+            h->slot_watch = tp.cap < h->cap_alloc - h->cap_alloc % kOct;
           }
           CHK(dev_alloc(h, &h->t_cnt, (kOct + 1) * (size_t)tp.ntiles + 3));
           CHK(dev_alloc(h, &h->t_oct, 2 * (size_t)tp.ntiles));

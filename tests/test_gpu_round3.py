@@ -71,44 +71,51 @@ def _largest_population(c, field, rsd):
     return int(np.bincount(tile * 8 + octant).max())
 
 
-def _policy(seg, maxc, overflowed):
-    """adapt_slots (bchmc.hip): segments of 1.5x the largest population; up when one overflowed or is more than 7/8
-    full, down when that is below 60 % of the current size."""
-    want = ((3 * maxc) // 2 + 16 + 7) // 8 * 8
-    if overflowed or 8 * maxc > 7 * seg:
-        return max(want, seg + 8)
-    if 5 * want < 3 * seg:
-        return want
-    return seg
-
-
 def test_record_slots_follow_the_measured_populations(monkeypatch):
     """The one-pass binning starts with whatever partition it is given (here: far too small), runs the exact two-pass sort
-    for the evaluation that overflowed, and re-partitions its allocation to 1.5x the largest (tile, octant) population
-    at the next synchronising call -- up and down, without reallocating."""
+    for the evaluation that overflowed, and extends the partition to its whole allocation at the next synchronising
+    call; a field whose 1.5x largest (tile, octant) population does not fit the allocation gets the array reallocated
+    for it.  It never shrinks (measured: nothing to gain, overflow to lose)."""
     monkeypatch.setenv("BCHMC_SORT_CAP", "64")             # 8 slots per (tile, octant): every tile overflows
     c = Case(Nx=32, likelihood=1, rsd_model=1)
     e = c.engine()
     i0 = e.tile_info()
     assert i0["one_pass"] == 1 and i0["cap"] == 64 and i0["cap_alloc"] >= 16 * 1024
-    seg = 8
-    # candidates ordered by their largest population, visited as: largest, largest again, smallest, largest -- the rule
-    # below then says "up", "same", "down" (if the ratio is below 60 %) and "up"
-    cand = sorted((s * c.truth for s in (0.02, 0.3, 1.0, 4.0)), key=lambda fld: _largest_population(c, fld, 1))
-    fields = [cand[-1], cand[-1], cand[0], cand[-1]]
+    fields = sorted((s * c.truth for s in (0.02, 0.3, 1.0, 4.0)), key=lambda fld: _largest_population(c, fld, 1))
     caps = []
-    for k, fld in enumerate(fields):
+    for fld in (fields[0], fields[0], fields[-1], fields[0]):
         dX = c.oracle.Lag2Eul(fld, rsd=1)[0]
         e.forward(fld, 1)                                  # exact whichever sort ran; synchronises: adapt_slots
         assert rel_l2(e.fetch("deltaX"), dX) < TOL_FIELD
-        maxc = _largest_population(c, fld, 1)
-        seg = _policy(seg, maxc, overflowed=maxc > seg)
         info = e.tile_info()
         caps.append(info["cap"])
-        assert info["cap"] == 8 * seg, (k, maxc, caps)
-        assert info["cap_alloc"] == i0["cap_alloc"] and info["one_pass"] == 1
-    assert caps[0] > 64 and caps[1] == caps[0]             # grown once, then stable on the same field
-    assert caps[2] <= caps[1] <= caps[3] or caps[2] == caps[1]
+        maxc = _largest_population(c, fld, 1)
+        assert info["one_pass"] == 1 and info["cap"] % 8 == 0 and info["cap"] == info["cap_alloc"] - info["cap_alloc"] % 8
+        assert 8 * maxc <= 7 * (info["cap"] // 8)          # room for the field just seen, with the 1/8 margin
+    assert caps[0] >= i0["cap_alloc"] - 7 and caps[1] == caps[0]   # extended to the whole allocation, then stable
+    assert caps[2] >= caps[1] and caps[3] == caps[2]       # never shrinks
+    e.close()
+
+
+def test_record_array_is_reallocated_from_the_measured_population(monkeypatch):
+    """BCHMC_SORT_CAP above the default allocation is not needed to hold a strongly clustered field: the array grows
+    to 1.5x its largest population (+25 %) at the synchronising call after the overflow."""
+    c = Case(Nx=32, likelihood=1, rsd_model=1)
+    e = c.engine()
+    i0 = e.tile_info()
+    fld = 40.0 * c.truth                                   # displacements of many cells: strongly clustered
+    maxc = _largest_population(c, fld, 1)
+    dX = c.oracle.Lag2Eul(fld, rsd=1)[0]
+    e.forward(fld, 1)
+    assert rel_l2(e.fetch("deltaX"), dX) < TOL_FIELD
+    info = e.tile_info()
+    if 8 * maxc > 7 * (i0["cap"] // 8):                    # it did not fit: reallocated for it
+        want = ((3 * maxc) // 2 + 16 + 7) // 8 * 8 * 8
+        assert info["cap_alloc"] == want + want // 4 and info["cap"] == info["cap_alloc"] - info["cap_alloc"] % 8
+        e.forward(fld, 1)                                  # ... and the one-pass binning holds it now
+        assert e.tile_info()["cap"] == info["cap"] and rel_l2(e.fetch("deltaX"), dX) < TOL_FIELD
+    else:
+        assert info["cap"] == i0["cap"]
     e.close()
 
 
