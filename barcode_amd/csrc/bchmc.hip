@@ -138,6 +138,7 @@ struct bchmc_handle {
   long long cap_alloc = 0;  // record slots per tile the array srec was allocated for; tp.cap <= cap_alloc is the part in use
   long long cap_wanted = 0; // > cap_alloc: what the next synchronising call should reallocate to (0 = nothing pending)
   bool cap_pinned = false;  // BCHMC_SORT_CAP_FIXED=1: the partition never adapts (A/B runs)
+  long long cap_budget = 0; // most record slots per tile the array may ever be reallocated for (a quarter of the device)
   bool slot_watch = true;   // the populations seen last were close to the segment size (or unknown yet): a long
                             // trajectory polls the binning's flag every few steps instead of only at its end
   int *h_slots = nullptr;   // pinned: two snapshots of {sticky overflow stamp, largest population} for those polls
@@ -391,24 +392,45 @@ int *slot_words(bchmc_handle *h) { return h->t_cnt + (kOct + 1) * (size_t)h->tp.
 int realloc_slots(bchmc_handle *h, long long cap) {
   HIPCHK(hipStreamSynchronize(h->stream));  // rare path: the record slots are about to be replaced
   const long long mean_occ = (long long)h->tp.tx * h->tp.ty * h->tp.tz;
+  const bool verbose = env_on("BCHMC_VERBOSE");
   if (cap > 64 * std::max<long long>(mean_occ, 64) || cap >= (1ll << 30)) {
     // a (tile, octant) holding more than ~40x its mean is a pathological field: keep the two-pass sort, not more memory
     h->sort_direct = false;
+    if (verbose) fprintf(stderr, "bchmc: %lld record slots per tile wanted: one-pass binning given up\n", cap);
     return BCHMC_OK;
   }
-  // never fewer than N records: the two-pass sort packs all particles
-  const size_t nrec = std::max<size_t>((size_t)h->g.N, (size_t)cap * h->tp.ntiles);
-  void *nrecs = nullptr;
-  if (hipMalloc(&nrecs, nrec * 4 * h->esz) != hipSuccess) {
-    (void)hipGetLastError();
-    h->sort_direct = false;  // the existing array holds >= N records: enough for the two-pass sort
+  // Memory budget: the records may take a quarter of the device (or what they took at creation).  A field clustered
+  // beyond that -- the mock-data truth field at 512^3 has a (tile, octant) of 3661 particles, 29x the mean, and 1.5x
+  // that would be 231 GB of slots -- keeps the array as it is: the evaluations that overflow run the exact two-pass
+  // sort (512^3 fp64: binning 2.7 -> 6.6 ms, scatter 6.5 -> 8.5 ms for those evaluations only).
+  if (cap > h->cap_budget) cap = h->cap_budget - h->cap_budget % kOct;
+  if (cap <= h->cap_alloc) {
+    if (verbose) fprintf(stderr, "bchmc: record slots stay at %lld per tile (memory budget %lld): overflowing evaluations "
+                                 "run the two-pass sort\n", h->cap_alloc, h->cap_budget);
     return BCHMC_OK;
   }
+  // The old array goes first (its contents are rebuilt by the next binning anyway): at 512^3 fp64 it is 69 GB, and the
+  // new one next to it would not fit.  Never fewer than N records: the two-pass sort packs all particles.
   (void)hipFree(h->srec);
-  h->srec = nrecs;
-  h->cap_alloc = cap;
-  if (env_on("BCHMC_VERBOSE")) fprintf(stderr, "bchmc: record array reallocated for %lld slots per tile\n", cap);
-  return BCHMC_OK;
+  h->srec = nullptr;
+  h->sorted_valid = false;
+  for (long long c : {cap, h->cap_alloc, 0ll}) {
+    const size_t nrec = std::max<size_t>((size_t)h->g.N, (size_t)c * h->tp.ntiles);
+    if (hipMalloc(&h->srec, nrec * 4 * h->esz) == hipSuccess) {
+      if (c == cap) {
+        h->cap_alloc = cap;
+        if (verbose) fprintf(stderr, "bchmc: record array reallocated for %lld slots per tile\n", cap);
+      } else {
+        if (verbose) fprintf(stderr, "bchmc: no memory for %lld record slots per tile: %s\n", cap,
+                             c ? "kept the old size, overflowing steps run the two-pass sort" : "one-pass binning given up");
+        if (c == 0) h->sort_direct = false;
+      }
+      return BCHMC_OK;
+    }
+    (void)hipGetLastError();
+    h->srec = nullptr;
+  }
+  return h->fail(BCHMC_ERR_NOMEM, "no device memory for the particle records");
 }
 
 // sticky: segment size stamped by an overflowing binning (0 = none); maxc: largest (tile, octant) population since the
@@ -420,13 +442,16 @@ int adapt_slots(bchmc_handle *h, int sticky, int maxc, bool may_realloc) {
   if (maxc <= 0 && !ovf) return BCHMC_OK;
   const long long whole = h->cap_alloc - h->cap_alloc % kOct;
   h->slot_watch = h->tp.cap < whole && (ovf || 4ll * maxc > 3 * seg);  // room left to extend into: keep an eye on it
-  if (!ovf && 8ll * maxc <= 7 * seg) return BCHMC_OK;
+  // extend into the allocation when a segment is 7/8 full; reallocate only for one that actually overflowed
+  if (!ovf && !(h->tp.cap < whole && 8ll * maxc > 7 * seg)) return BCHMC_OK;
   long long want = ((3ll * maxc) / 2 + 16 + 7) / 8 * 8;  // segments of 1.5x the largest population
   if (want <= seg) want = 2 * seg;                        // overflow without a population figure: double
   long long ncap = std::max(want * kOct, whole);          // at least everything that is allocated
   if (ncap > whole) {
-    if (may_realloc) {
-      CHK(realloc_slots(h, ncap + ncap / 4));
+    if (!ovf) {
+      ncap = whole;
+    } else if (may_realloc) {
+      CHK(realloc_slots(h, ncap + ncap / 4));  // may keep the array as it is (memory budget)
       if (!h->sort_direct) return BCHMC_OK;
       h->cap_wanted = 0;
       ncap = h->cap_alloc - h->cap_alloc % kOct;
@@ -461,6 +486,8 @@ int read_ctl(bchmc_handle *h, unsigned long long *steps_done) {
     if (h->cap_wanted > h->cap_alloc) {  // a poll inside a trajectory could not grow the array: do it now
       CHK(realloc_slots(h, h->cap_wanted + h->cap_wanted / 4));
       h->cap_wanted = 0;
+      h->tp.cap = (int)(h->cap_alloc - h->cap_alloc % kOct);
+      h->sorted_valid = false;
     }
     CHK(adapt_slots(h, words[0], words[1], true));
   }
@@ -2082,6 +2109,11 @@ int bchmc_create(const bchmc_config *cfg, bchmc_handle **out) {
             tp.cap = (int)(std::getenv("BCHMC_SORT_CAP") ? cap : h->cap_alloc - h->cap_alloc % kOct);
             nrec = std::max<size_t>(N, (size_t)h->cap_alloc * tp.ntiles);
             h->slot_watch = tp.cap < h->cap_alloc - h->cap_alloc % kOct;
+            {
+              size_t free_b = 0, total_b = 0;
+              HIPCHK(hipMemGetInfo(&free_b, &total_b));
+              h->cap_budget = std::max<long long>(h->cap_alloc, (long long)(total_b / 4 / ((size_t)tp.ntiles * 4 * e)));
+            }
           }
           CHK(dev_alloc(h, &h->t_cnt, (kOct + 1) * (size_t)tp.ntiles + 3));
           CHK(dev_alloc(h, &h->t_oct, 2 * (size_t)tp.ntiles));
