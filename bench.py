@@ -47,6 +47,9 @@ def parse():
                          "`sustained` next to the headline (untimed part of the run; 0 switches it off)")
     ap.add_argument("--no-rccl-probe", action="store_true",
                     help="N > 1 on nccl: skip the untimed ncclAllGather through the library's own RCCL transport")
+    ap.add_argument("--force-rccl-probe", action="store_true",
+                    help="rehearsal: run that probe whatever the backend (two ranks on one device make RCCL refuse: the "
+                         "error path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-nx", type=int, default=0, help="grid of the CPU-baseline sample (default: same as --nx)")
     ap.add_argument("--no-kernel-profile", action="store_true")
@@ -200,18 +203,21 @@ def two_chain_throughput(params, fields, arrays, dev, local_rank, eps, steps, pr
                 note="opt-in deployment mode for many-chain sampling; the headline `value` is one chain on the whole GPU")
 
 
-def rccl_native_probe(group, dist, dev, rank, world, eps, steps, timeout_s=90.0):
+def rccl_native_probe(dist, dev, rank, world, eps, steps, timeout_s=90.0):
     """Untimed: the same exchange once more through the LIBRARY's own RCCL transport (bchmc_comm_create: ncclCommInitRank
     + ncclAllGather behind the C ABI, what a barcode/main.cc-driven chain uses), whatever transport the timed exchange
-    ran on.  Runs in a thread with a deadline, so a transport that cannot come up is reported, not waited for."""
+    ran on.  Isolated from the measurement: the 128-byte id travels over a gloo side group (so nothing of the probe is
+    queued on torch's RCCL process group), the library's communicator is its own, and the work runs in a thread with a
+    deadline -- a transport that cannot come up is reported (`hung`), not waited for."""
     import threading
     from barcode_amd import engine as _eng
     res = dict(ok=False)
+    side = dist.new_group(backend="gloo")  # collective: every rank, main thread
 
     def work():
         try:
             uid = [_eng.Comm.unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(uid, src=0)
+            dist.broadcast_object_list(uid, src=0, group=side)
             c = _eng.Comm(rank, world, device=dev.index, unique_id=uid[0])
             got = c.exchange([(eps, True, steps)])
             info = c.info()
@@ -423,8 +429,13 @@ def main():
                                 collective["ranks_seen"] == list(range(world)) and collective["records"] == world)
     else:
         collective["ok"] = collective["ranks_seen"] == [0] and collective["records"] == 1
-    if distributed and args.backend == "nccl" and not args.single_device and not args.no_rccl_probe:
-        collective["rccl_native"] = rccl_native_probe(group, dist, dev, rank, world, eps, args.steps)
+    if distributed and ((args.backend == "nccl" and not args.single_device and not args.no_rccl_probe) or
+                        args.force_rccl_probe):
+        try:
+            collective["rccl_native"] = rccl_native_probe(dist, dev, rank, world, eps, args.steps,
+                                                          timeout_s=20.0 if args.force_rccl_probe else 90.0)
+        except Exception as e:  # the probe must never cost the measurement
+            collective["rccl_native"] = dict(ok=False, error="%s: %s" % (type(e).__name__, e))
     if done != args.steps:
         print("bench.py: runaway guard fired after %d of %d steps" % (done, args.steps), file=sys.stderr)
     finite = bool(torch.isfinite(q1).all().item() and torch.isfinite(p1).all().item())
@@ -535,8 +546,11 @@ def main():
                                              ok=bool(rq < tol and rp < tol),
                                              oracle="oracle/liboracle_omp.so (parity unpinned: no reference vectors exist)")
         print(json.dumps(out))
+    sys.stdout.flush()
     if distributed:
         dist.barrier()
+        if (collective.get("rccl_native") or {}).get("hung"):
+            os._exit(0)  # a thread is stuck inside the probe's communicator set-up: do not wait for its teardown
         dist.destroy_process_group()
 
 

@@ -262,7 +262,8 @@ def test_bench_self_launch_two_ranks_reports_what_the_collective_saw():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--single-device", "--backend",
                         "gloo", "--nx", "32", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
-                        "--no-kernel-profile"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=env)
+                        "--no-kernel-profile", "--force-rccl-probe"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       timeout=600, env=env)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -272,3 +273,7 @@ def test_bench_self_launch_two_ranks_reports_what_the_collective_saw():
     assert c["backend"] == "gloo" and c["transport"] == "custom" and c["world_seen"] == 2
     assert c["ranks_seen"] == [0, 1] and c["records"] == 2 and c["consistent_across_ranks"] and c["ok"]
     assert d["config"]["steps_done"] == 3 and d["config"]["finite"]
+    # the untimed probe of the library's own RCCL transport ran too (forced here: two ranks on one device, which RCCL
+    # refuses) -- it reports the refusal and costs the measurement nothing; with one GPU per rank it reports world / ranks
+    probe = c["rccl_native"]
+    assert probe["ok"] is False and "ncclCommInitRank" in probe["error"] and not probe.get("hung")
