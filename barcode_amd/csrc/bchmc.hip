@@ -391,19 +391,13 @@ int *slot_words(bchmc_handle *h) { return h->t_cnt + (kOct + 1) * (size_t)h->tp.
 
 int realloc_slots(bchmc_handle *h, long long cap) {
   HIPCHK(hipStreamSynchronize(h->stream));  // rare path: the record slots are about to be replaced
-  const long long mean_occ = (long long)h->tp.tx * h->tp.ty * h->tp.tz;
   const bool verbose = env_on("BCHMC_VERBOSE");
-  if (cap > 64 * std::max<long long>(mean_occ, 64) || cap >= (1ll << 30)) {
-    // a (tile, octant) holding more than ~40x its mean is a pathological field: keep the two-pass sort, not more memory
-    h->sort_direct = false;
-    if (verbose) fprintf(stderr, "bchmc: %lld record slots per tile wanted: one-pass binning given up\n", cap);
-    return BCHMC_OK;
-  }
   // Memory budget: the records may take a quarter of the device (or what they took at creation).  A field clustered
   // beyond that -- the mock-data truth field at 512^3 has a (tile, octant) of 3661 particles, 29x the mean, and 1.5x
-  // that would be 231 GB of slots -- keeps the array as it is: the evaluations that overflow run the exact two-pass
-  // sort (512^3 fp64: binning 2.7 -> 6.6 ms, scatter 6.5 -> 8.5 ms for those evaluations only).
-  if (cap > h->cap_budget) cap = h->cap_budget - h->cap_budget % kOct;
+  // that would be 231 GB of slots -- keeps the array at the budget: the evaluations that overflow run the exact two-pass
+  // sort (512^3 fp64: binning 2.7 -> 6.6 ms, scatter 6.5 -> 8.5 ms for those evaluations only), all others stay on
+  // the one-pass path (one exceptional field, e.g. the truth field of a mock-data run, must not cost the chain that).
+  if (cap > h->cap_budget || cap >= (1ll << 30)) cap = std::min<long long>(h->cap_budget, (1ll << 30) - kOct) / kOct * kOct;
   if (cap <= h->cap_alloc) {
     if (verbose) fprintf(stderr, "bchmc: record slots stay at %lld per tile (memory budget %lld): overflowing evaluations "
                                  "run the two-pass sort\n", h->cap_alloc, h->cap_budget);
