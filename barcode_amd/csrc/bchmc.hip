@@ -101,6 +101,8 @@ struct bchmc_handle {
   hipEvent_t stg_ev[2] = {nullptr, nullptr};
   size_t stg_chunk = 0;
   int stg_threads = 1;
+  hipStream_t copy_stream = nullptr;  // uploads that run beside compute (the momenta of a host-array trajectory)
+
   int4 *hull = nullptr;
   int hull_n = 0;
   int reach = 0;
@@ -619,10 +621,11 @@ int stg_init(bchmc_handle *h) {
 
 // host -> device, enqueued on the handle's stream; returns once the host array has been read completely (the caller
 // may reuse it), the last DMA chunks may still be in flight on the stream
-int h2d(bchmc_handle *h, void *dst, const void *src, size_t bytes) {
+int h2d(bchmc_handle *h, void *dst, const void *src, size_t bytes, hipStream_t stream = nullptr) {
+  if (!stream) stream = h->stream;
   if (bytes <= ((size_t)1 << 20)) {
-    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream));
+    HIPCHK(hipStreamSynchronize(stream));
     return BCHMC_OK;
   }
   CHK(stg_init(h));
@@ -633,8 +636,8 @@ int h2d(bchmc_handle *h, void *dst, const void *src, size_t bytes) {
     const size_t off = c * chunk, len = std::min(chunk, bytes - off);
     if (c >= 2) HIPCHK(hipEventSynchronize(h->stg_ev[b]));  // DMA of chunk c - 2 has left this buffer
     par_memcpy(h->stg[b], (const char *)src + off, len, h->stg_threads);
-    HIPCHK(hipMemcpyAsync((char *)dst + off, h->stg[b], len, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipEventRecord(h->stg_ev[b], h->stream));
+    HIPCHK(hipMemcpyAsync((char *)dst + off, h->stg[b], len, hipMemcpyHostToDevice, stream));
+    HIPCHK(hipEventRecord(h->stg_ev[b], stream));
   }
   // the staging buffers are reused by the next call: wait for the two DMAs still in flight
   HIPCHK(hipEventSynchronize(h->stg_ev[0]));
@@ -1263,6 +1266,63 @@ struct Pipe {
   // variants of k_step_boundary_x); BCHMC_NO_PLANES_ENDS=1 keeps those on the 3-D plans
   static bool planes_everywhere(const bchmc_handle *h) { return planes_on(h) && !env_on("BCHMC_NO_PLANES_ENDS"); }
 
+  // How a trajectory runs on this handle: which model produces the displacement, whether the fused step boundary
+  // applies, the constant that turns q^ into the model's k-space input.
+  struct TrajPlan {
+    double a, c_za;
+    bool alpt_x, fused_za, fused;
+  };
+  static TrajPlan traj_plan(bchmc_handle *h) {
+    TrajPlan tp;
+    tp.a = h->c.grad_psi_prior_factor;
+    // the k-space kernels produce the Zel'dovich Psi^ as a by-product; the ALPT model needs its own pipeline
+    // ... on the 2-D plans (alpt_planes) the step boundary leaves that pipeline's two input fields instead of Psi^
+    const bool alpt = uses_alpt(h, h->c.rsd_model) && h->c.likelihood != 3;
+    tp.alpt_x = alpt && !h->mass_rs && !env_on("BCHMC_NO_FUSE") && alpt_planes(h);
+    tp.fused_za = (h->c.likelihood != 3) && !alpt;
+    tp.c_za = tp.alpt_x ? h->c.deltaQ_factor / (double)h->g.N : -h->c.D1 * h->c.deltaQ_factor / (double)h->g.N;
+    tp.fused = (tp.fused_za || tp.alpt_x) && !h->mass_rs && !env_on("BCHMC_NO_FUSE");
+    return tp;
+  }
+
+  // gradient_psi at the trajectory's start state q^ = qk (HMC.cc:279-280) into gk; needs nothing of the momenta.
+  // like_i: where to leave the -log L partials of this evaluation's forward model (may be null).
+  static int initial_force(bchmc_handle *h, const TrajPlan &pl, double *like_i, void *g0_out) {
+    int like_mode = 2;
+    double b = 0.;
+    if (pl.fused && planes_everywhere(h)) {
+      // the same evaluation on the 2-D plans: Psi^ with its inverse x passes, V^ assembled after forward x passes
+      StepCtl nc{h->stop, h->steps_done, nullptr, 0., 0};
+      {
+        ProfScope ps(h, BCHMC_K_KSPACE_DRIFT_ZA);
+        if (pl.alpt_x)
+          CHK((launch_boundary_x<BX_FIRST, true>(h, C(h->qk), nullptr, nullptr, nullptr, nullptr, 0., 0., 0., 0., pl.c_za,
+                                                 nullptr, nc, nullptr, nullptr)));
+        else
+          CHK(launch_boundary_x<BX_FIRST>(h, C(h->qk), nullptr, nullptr, nullptr, nullptr, 0., 0., 0., 0., pl.c_za, nullptr,
+                                          nc, nullptr, nullptr));
+      }
+      h->alpt_pending = pl.alpt_x;
+      h->planes_c2r = h->planes_r2c = true;
+      const int rc = force_sources(h, true, &like_mode, &b);
+      h->planes_c2r = h->planes_r2c = false;
+      CHK(rc);
+      if (like_mode != 0) return h->fail(BCHMC_ERR_STATE, "planes mode without the three V components");
+      if (like_i) CHK(tap_loglike(h, like_i));
+      h->prop_g_valid = false;
+      ProfScope ps(h, BCHMC_K_KSPACE_FORCE_KICK);
+      CHK(launch_boundary_x<BX_LAST>(h, C(h->qk), nullptr, nullptr, nullptr, nullptr, pl.a, b, 0., 0., 0., nullptr, nc,
+                                     nullptr, C(h->gk)));
+    } else {
+      CHK(force_sources(h, false, &like_mode, &b));
+      if (like_i) CHK(tap_loglike(h, like_i));
+      CHK(launch_assemble<false>(h, pl.a, b, like_mode, 0., nullptr));
+    }
+    if (g0_out)
+      HIPCHK(hipMemcpyAsync(g0_out, h->gk, 2 * (size_t)h->g.Nhp * sizeof(T), hipMemcpyDeviceToDevice, h->stream));
+    return BCHMC_OK;
+  }
+
   // Hamiltonian_EoM (HMC.cc:275-365) on the k-space state already in (qk, pk).
   // g0_in: the gradient at the start state if the caller has it (the evaluation of HMC.cc:279 is skipped);
   // g0_out: where to keep a copy of it when it is evaluated here.
@@ -1279,49 +1339,13 @@ struct Pipe {
     k_init_ctl<<<1, 1, 0, h->stream>>>(h->stop, h->steps_done, (unsigned long long)neps);
     HIPCHK(hipGetLastError());
 
-    const double a = h->c.grad_psi_prior_factor;
+    const TrajPlan pl = traj_plan(h);
+    const double a = pl.a, c_za = pl.c_za;
+    const bool alpt_x = pl.alpt_x, fused_za = pl.fused_za, fused = pl.fused;
     int like_mode = 2;
     double b = 0.;
     // 0) gradient at t = 0 (HMC.cc:279-280)
-    // the k-space kernels produce the Zel'dovich Psi^ as a by-product; the ALPT model needs its own pipeline
-    // ... on the 2-D plans (alpt_planes) the step boundary leaves that pipeline's two input fields instead of Psi^
-    const bool alpt = uses_alpt(h, h->c.rsd_model) && h->c.likelihood != 3;
-    const bool alpt_x = alpt && !h->mass_rs && !env_on("BCHMC_NO_FUSE") && alpt_planes(h);
-    const bool fused_za = (h->c.likelihood != 3) && !alpt;
-    const double c_za = alpt_x ? h->c.deltaQ_factor / (double)h->g.N : -h->c.D1 * h->c.deltaQ_factor / (double)h->g.N;
-    const bool fused = (fused_za || alpt_x) && !h->mass_rs && !env_on("BCHMC_NO_FUSE");
-    if (!g0_in) {
-      if (fused && planes_everywhere(h)) {
-        // the same evaluation on the 2-D plans: Psi^ with its inverse x passes, V^ assembled after forward x passes
-        StepCtl nc{h->stop, h->steps_done, nullptr, 0., 0};
-        {
-          ProfScope ps(h, BCHMC_K_KSPACE_DRIFT_ZA);
-          if (alpt_x)
-            CHK((launch_boundary_x<BX_FIRST, true>(h, C(h->qk), nullptr, nullptr, nullptr, nullptr, 0., 0., 0., 0., c_za,
-                                                   nullptr, nc, nullptr, nullptr)));
-          else
-            CHK(launch_boundary_x<BX_FIRST>(h, C(h->qk), nullptr, nullptr, nullptr, nullptr, 0., 0., 0., 0., c_za, nullptr,
-                                            nc, nullptr, nullptr));
-        }
-        h->alpt_pending = alpt_x;
-        h->planes_c2r = h->planes_r2c = true;
-        const int rc = force_sources(h, true, &like_mode, &b);
-        h->planes_c2r = h->planes_r2c = false;
-        CHK(rc);
-        if (like_mode != 0) return h->fail(BCHMC_ERR_STATE, "planes mode without the three V components");
-        if (tap && tap->like_i) CHK(tap_loglike(h, tap->like_i));
-        h->prop_g_valid = false;
-        ProfScope ps(h, BCHMC_K_KSPACE_FORCE_KICK);
-        CHK(launch_boundary_x<BX_LAST>(h, C(h->qk), nullptr, nullptr, nullptr, nullptr, a, b, 0., 0., 0., nullptr, nc,
-                                       nullptr, C(h->gk)));
-      } else {
-        CHK(force_sources(h, false, &like_mode, &b));
-        if (tap && tap->like_i) CHK(tap_loglike(h, tap->like_i));
-        CHK(launch_assemble<false>(h, a, b, like_mode, 0., nullptr));
-      }
-      if (g0_out)
-        HIPCHK(hipMemcpyAsync(g0_out, h->gk, 2 * (size_t)h->g.Nhp * sizeof(T), hipMemcpyDeviceToDevice, h->stream));
-    }
+    if (!g0_in) CHK(initial_force(h, pl, tap ? tap->like_i : nullptr, g0_out));
     const void *g_first = g0_in ? g0_in : h->gk;
     if (neps == 0) return BCHMC_OK;  // HMC.cc:284 loops zero times: the state is returned as it came
 
@@ -1535,9 +1559,11 @@ struct Pipe {
   // left in dstage (fast mode: the caller transforms).
   // Fast mode only: g0_in / like0 = the gradient and -log L at the start state when the caller carries them;
   // g0_out = where to keep the gradient at the start state otherwise.
+  // g0_ready (fast mode): gk already holds the gradient at the start state and the partials of its -log L are in
+  // part6's third slot (host_prologue evaluated them while the momenta were still on their way).
   static int attempt_core(bchmc_handle *h, double eps, uint64_t neps, const double *d_q0, const double *d_p0,
                           const void *src_qk, const void *src_pk, double terms[6], uint64_t *steps_done,
-                          const void *g0_in = nullptr, double like0 = 0., void *g0_out = nullptr) {
+                          const void *g0_in = nullptr, double like0 = 0., void *g0_out = nullptr, bool g0_ready = false) {
     CHK(check_inputs(h));
     if (eps > 2.) eps = 2.;
     const size_t cbytes = 2 * (size_t)h->g.Nhp * sizeof(T);
@@ -1556,8 +1582,9 @@ struct Pipe {
       k_parseval<T><<<kRedBlocks, 256, 0, h->stream>>>(h->g, C(h->qk), h->wS, P + kRedBlocks);
       HIPCHK(hipGetLastError());
     }
+    if (g0_ready && fast) g0_in = h->gk;
     Tap tap{g0_in ? nullptr : P + 2 * kRedBlocks, P + 5 * kRedBlocks};
-    if (g0_in) HIPCHK(hipMemsetAsync(P + 2 * kRedBlocks, 0, kRedBlocks * sizeof(double), h->stream));
+    if (g0_in && !g0_ready) HIPCHK(hipMemsetAsync(P + 2 * kRedBlocks, 0, kRedBlocks * sizeof(double), h->stream));
     CHK(trajectory(h, eps, neps, fast ? &tap : nullptr, fast ? g0_in : nullptr, fast ? g0_out : nullptr));
     uint64_t done = 0;
     if (fast) {
@@ -1574,7 +1601,7 @@ struct Pipe {
         for (int i = 0; i < kRedBlocks; i++) s += hp[(size_t)t * kRedBlocks + i];
         terms[t] = (t == 0 || t == 1 || t == 3 || t == 4) ? s / (2. * N) : s;
       }
-      if (g0_in) terms[2] = like0;
+      if (g0_in && !g0_ready) terms[2] = like0;
       if (done < neps) {
         // runaway guard fired (HMC.cc:360-364): the tapped forward model is not the final state's; redo it
         CHK(displacement(h, h->c.likelihood == 1 ? h->c.deltaQ_factor : 1., h->c.likelihood == 1 ? h->c.rsd_model : 0));
@@ -1625,14 +1652,17 @@ struct Pipe {
   }
 
   // Hamiltonian_EoM for host arrays already staged in dstage (q0) and dstage + N (p0): the same single pass, so the
-  // energies of both ends come with it (bchmc_delta_hamiltonian answers from them when it is asked about these very
-  // arrays, which is what HamiltonianMC does next, HMC.cc:455-459).  Leaves (q1, p1) in dstage, dstage + N.
-  static int leapfrog_host_core(bchmc_handle *h, double eps, uint64_t neps, double terms[6], uint64_t *steps_done) {
+  // energies of both ends come with it (bchmc_leapfrog_dh hands them to the caller, who asks for them next,
+  // HMC.cc:455-459).  Leaves (q1, p1) in dstage, dstage + N.
+  // prologue_done: host_prologue has run (FFT[q0] is in qk, gk and the -log L partials are the start state's).
+  static int leapfrog_host_core(bchmc_handle *h, double eps, uint64_t neps, double terms[6], uint64_t *steps_done,
+                                bool prologue_done = false) {
     double *dq = h->dstage, *dp = h->dstage + h->g.N;
     if (attempt_is_fast(h, neps)) {
-      CHK(r2c_state(h, dq, h->ioq, h->qk));
+      if (!prologue_done) CHK(r2c_state(h, dq, h->ioq, h->qk));
       CHK(r2c_state(h, dp, h->iop, h->pk));
-      CHK(attempt_core(h, eps, neps, nullptr, nullptr, nullptr, nullptr, terms, steps_done));
+      CHK(attempt_core(h, eps, neps, nullptr, nullptr, nullptr, nullptr, terms, steps_done, nullptr, 0., nullptr,
+                       prologue_done));
       CHK(c2r_state(h, h->qk, h->ioq, dq));
       CHK(c2r_state(h, h->pk, h->iop, dp));
     } else {
@@ -1641,6 +1671,20 @@ struct Pipe {
       CHK(attempt_core(h, eps, neps, dq, dp, nullptr, nullptr, terms, steps_done));
     }
     return BCHMC_OK;
+  }
+
+  // Everything of a host-array trajectory that needs q0 only -- its transform and the force evaluation of HMC.cc:279 --
+  // enqueued before the momenta are uploaded, so that their PCIe transfer (3 ms per 134 MB array) runs beside it.
+  static int host_prologue(bchmc_handle *h) {
+    CHK(check_inputs(h));
+    if (!h->part6) CHK(dev_alloc(h, &h->part6, (size_t)6 * kRedBlocks));
+    k_init_ctl<<<1, 1, 0, h->stream>>>(h->stop, h->steps_done, 0ull);  // a stop flag left by an earlier trajectory
+    HIPCHK(hipGetLastError());
+    CHK(r2c_state(h, h->dstage, h->ioq, h->qk));
+    return initial_force(h, traj_plan(h), h->part6 + 2 * kRedBlocks, nullptr);
+  }
+  static bool host_prologue_applies(const bchmc_handle *h, uint64_t neps) {
+    return attempt_is_fast(h, neps) && !env_on("BCHMC_NO_UPLOAD_OVERLAP");
   }
 
   // kinetic_term (HMC.cc:64-121) of the momenta in the ABI (double) device array d_p: 1/2 p^T M^-1 p.
@@ -2188,6 +2232,7 @@ void bchmc_destroy(bchmc_handle *h) {
   for (int f = 0; f < 6; f++)
     if (h->in_arr[f]) (void)hipFree(h->in_arr[f]);
   if (h->h_part) (void)hipHostFree(h->h_part);
+  if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
   if (h->h_slots) (void)hipHostFree(h->h_slots);
   for (hipEvent_t e : h->slot_ev)
     if (e) (void)hipEventDestroy(e);
@@ -2268,12 +2313,23 @@ int bchmc_leapfrog_dh(bchmc_handle *h, const double *q0, const double *p0, doubl
   const size_t N = (size_t)h->g.N, bytes = N * sizeof(double);
   double *dq = h->dstage, *dp = h->dstage + N;
   CHK(h2d(h, dq, q0, bytes));
-  CHK(h2d(h, dp, p0, bytes));
+  // The force evaluation at the start state (HMC.cc:279) needs q0 only: it is enqueued now, and the momenta cross PCIe
+  // on a second stream while it runs (h2d returns when its last chunk has arrived, so no event is needed afterwards).
+  const bool prologue = DISPATCH(h, host_prologue_applies(h, neps));
+  if (prologue) {
+    CHK(DISPATCH(h, host_prologue(h)));
+    if (!h->copy_stream) {
+      HIPCHK(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    }
+    CHK(h2d(h, dp, p0, bytes, h->copy_stream));
+  } else {
+    CHK(h2d(h, dp, p0, bytes));
+  }
   uint64_t done = 0;
   // one pass: the trajectory's own first and last force evaluation carry -log L of both ends, K and psi_prior are
   // Parseval sums of the k-space state (the resident chain's attempt_core); generic configurations evaluate the
   // energies around the trajectory without further transfers
-  CHK(DISPATCH(h, leapfrog_host_core(h, eps, neps, terms, &done)));
+  CHK(DISPATCH(h, leapfrog_host_core(h, eps, neps, terms, &done, prologue)));
   CHK(d2h(h, q1, dq, bytes));
   CHK(d2h(h, p1, dp, bytes));
   if (steps_done) *steps_done = done;
