@@ -1496,13 +1496,14 @@ struct Pipe {
     return BCHMC_OK;
   }
 
+  // prologue_done: plain_prologue has run (FFT[q0] is in qk and gk holds the gradient at the start state)
   static int leapfrog_core(bchmc_handle *h, const double *d_q0, const double *d_p0, double *d_q1, double *d_p1,
-                           double eps, uint64_t neps) {
+                           double eps, uint64_t neps, bool prologue_done = false) {
     CHK(check_inputs(h));
     if (eps > 2.) eps = 2.;  // HMC.cc:263-264
-    CHK(r2c_state(h, d_q0, h->ioq, h->qk));
+    if (!prologue_done) CHK(r2c_state(h, d_q0, h->ioq, h->qk));
     CHK(r2c_state(h, d_p0, h->iop, h->pk));
-    CHK(trajectory(h, eps, neps, nullptr));
+    CHK(trajectory(h, eps, neps, nullptr, prologue_done ? h->gk : nullptr));
     CHK(c2r_state(h, h->qk, h->ioq, d_q1));
     CHK(c2r_state(h, h->pk, h->iop, d_p1));
     return BCHMC_OK;
@@ -1682,6 +1683,14 @@ struct Pipe {
     HIPCHK(hipGetLastError());
     CHK(r2c_state(h, h->dstage, h->ioq, h->qk));
     return initial_force(h, traj_plan(h), h->part6 + 2 * kRedBlocks, nullptr);
+  }
+  // the same for the plain trajectory (bchmc_leapfrog): no energies, so no -log L partials to keep
+  static int plain_prologue(bchmc_handle *h) {
+    CHK(check_inputs(h));
+    k_init_ctl<<<1, 1, 0, h->stream>>>(h->stop, h->steps_done, 0ull);
+    HIPCHK(hipGetLastError());
+    CHK(r2c_state(h, h->dstage, h->ioq, h->qk));
+    return initial_force(h, traj_plan(h), nullptr, nullptr);
   }
   static bool host_prologue_applies(const bchmc_handle *h, uint64_t neps) {
     return attempt_is_fast(h, neps) && !env_on("BCHMC_NO_UPLOAD_OVERLAP");
@@ -2295,8 +2304,17 @@ int bchmc_leapfrog(bchmc_handle *h, const double *q0, const double *p0, double *
   const size_t N = (size_t)h->g.N, bytes = N * sizeof(double);
   double *dq = h->dstage, *dp = h->dstage + N;
   CHK(h2d(h, dq, q0, bytes));
-  CHK(h2d(h, dp, p0, bytes));
-  CHK(DISPATCH(h, leapfrog_core(h, dq, dp, dq, dp, eps, neps)));
+  // as in bchmc_leapfrog_dh: the start-state force evaluation is enqueued before the momenta are uploaded beside it
+  // (any configuration: the force never involves p; HMC.cc:284 with neps = 0 evaluates it too)
+  const bool prologue = !env_on("BCHMC_NO_UPLOAD_OVERLAP");
+  if (prologue) {
+    CHK(DISPATCH(h, plain_prologue(h)));
+    if (!h->copy_stream) HIPCHK(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    CHK(h2d(h, dp, p0, bytes, h->copy_stream));
+  } else {
+    CHK(h2d(h, dp, p0, bytes));
+  }
+  CHK(DISPATCH(h, leapfrog_core(h, dq, dp, dq, dp, eps, neps, prologue)));
   CHK(d2h(h, q1, dq, bytes));
   CHK(d2h(h, p1, dp, bytes));
   uint64_t done = 0;

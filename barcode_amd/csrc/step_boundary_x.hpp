@@ -3,6 +3,9 @@
 #pragma once
 #include "common.hpp"
 
+#ifndef BCHMC_BX_SWIZZLE
+#define BCHMC_BX_SWIZZLE 1
+#endif
 #ifndef BCHMC_BX_WAVES
 #define BCHMC_BX_WAVES 4
 #endif
@@ -179,7 +182,12 @@ k_step_boundary_x(Geo g, int log2n, const C2<T> *__restrict__ twiddle, C2<T> *Ck
   C2<T> *tw = s + (size_t)n * KB;                 // n / 2
   for (int t = threadIdx.x; t < n / 2; t += blockDim.x) tw[t] = twiddle[t];
   const int ntk = g.nhp / KB;
-  const int j = blockIdx.x / ntk, k0 = (blockIdx.x % ntk) * KB;
+  int bid = (int)blockIdx.x;
+#if BCHMC_BX_SWIZZLE
+  // workgroups are dealt round-robin to the 8 XCDs: give each XCD a contiguous range of (j, k0) columns
+  if ((gridDim.x & 7) == 0) bid = (bid & 7) * (int)(gridDim.x >> 3) + (bid >> 3);
+#endif
+  const int j = bid / ntk, k0 = (bid % ntk) * KB;
   const int c = threadIdx.x % KB, irow = threadIdx.x / KB;
   constexpr int rows = NT / KB, per = PER;
   const int k = k0 + c;

@@ -188,8 +188,14 @@ __device__ __forceinline__ int super_brick(const Geo &g, int sb, int m) {
   return sb * kBinPer + m;  // may run past the last brick: brick_particle then returns p >= N
 }
 
+// fp64: three workgroups per CU (12 waves) -- measured 6 % faster than the four the register count allows and 15 % faster
+// than two (scripts/bin_bench.hip, dynamic-LDS sweep): fewer concurrent record streams merge better in the L2.  fp32
+// (16-byte records): four are faster than three (0.228 against 0.252-0.263 ms at 256^3).
+#ifndef BCHMC_BIN_WAVES
+#define BCHMC_BIN_WAVES (sizeof(T) == 8 ? 3 : 4)
+#endif
 template <typename T>
-__global__ void __launch_bounds__(BCHMC_BIN_THREADS)
+__global__ void __launch_bounds__(BCHMC_BIN_THREADS) __attribute__((amdgpu_waves_per_eu(BCHMC_BIN_WAVES, BCHMC_BIN_WAVES)))
 k_bin_direct(Geo g, PosPar pp, SphPar sp, TilePar tp, int nsuper, const T *__restrict__ psi, int *__restrict__ cnt,
              int *__restrict__ ovf, RecQuad *__restrict__ srec, T *__restrict__ V, double *__restrict__ zero_part,
              T *__restrict__ rho_zero, long long *__restrict__ fix_zero) {
@@ -207,20 +213,48 @@ k_bin_direct(Geo g, PosPar pp, SphPar sp, TilePar tp, int nsuper, const T *__res
     __syncthreads();
     long long p[kBinLoop];
     int key[kBinLoop], slot[kBinLoop], local[kBinLoop], flag[kBinLoop];
+    int li[kBinLoop], lj[kBinLoop], lk[kBinLoop];
     T x[kBinLoop], y[kBinLoop], z[kBinLoop];
     const int tid = (int)threadIdx.x & 255, grp = (int)threadIdx.x >> 8;
+    // all displacement loads of the workgroup's bricks are issued before the first one is used: one memory round trip
+    // per super-brick instead of one per brick (the position arithmetic between them is ~500 instructions per brick)
+    // lattice coordinates of the super-brick once per workgroup (scalar divisions), its bricks by offsets: flattening
+    // each brick's number and dividing it apart again cost ~280 vector instructions per brick
+    constexpr int PJ = kBinPer >= 2 ? 2 : 1, PI = kBinPer >= 4 ? 2 : 1;
+    const bool lattice = (g.n & 15) == 0;
+    int sbi = 0, sbj = 0, sbk = 0;
+    if (lattice) {
+      const int nbz = g.n >> 4, nbys = (g.n >> 2) / PJ;
+      sbk = sb % nbz;
+      sbj = (sb / nbz) % nbys;
+      sbi = sb / (nbz * nbys);
+    }
 #pragma unroll
     for (int m = 0; m < kBinLoop; m++) {
-      int i, j, k;
-      p[m] = brick_particle(g, super_brick(g, sb, m * kBinGroups + grp), tid, i, j, k);
-      key[m] = -1;
-      slot[m] = local[m] = flag[m] = 0;
+      const int mm = m * kBinGroups + grp;
+      if (lattice) {
+        li[m] = (PI * sbi + mm / PJ) * 4 + (tid >> 6);
+        lj[m] = (PJ * sbj + mm % PJ) * 4 + ((tid >> 4) & 3);
+        lk[m] = sbk * 16 + (tid & 15);
+        p[m] = lk[m] + (long long)g.n * (lj[m] + (long long)g.n * li[m]);
+      } else {
+        p[m] = brick_particle(g, super_brick(g, sb, mm), tid, li[m], lj[m], lk[m]);
+      }
       x[m] = y[m] = z[m] = T(0);
       if (p[m] >= g.N) continue;
+      x[m] = psi[p[m]];
+      y[m] = psi[p[m] + g.N];
+      z[m] = psi[p[m] + 2 * g.N];
       // the bricks visit every lattice index once: clear the density the scatter accumulates into (no fill launch)
       if (rho_zero) rho_zero[p[m]] = T(0);
       if (fix_zero) fix_zero[p[m]] = 0;
-      particle_pos<T>(pp, i, j, k, psi[p[m]], psi[p[m] + g.N], psi[p[m] + 2 * g.N], x[m], y[m], z[m]);
+    }
+#pragma unroll
+    for (int m = 0; m < kBinLoop; m++) {
+      key[m] = -1;
+      slot[m] = local[m] = flag[m] = 0;
+      if (p[m] >= g.N) continue;
+      particle_pos<T>(pp, li[m], lj[m], lk[m], x[m], y[m], z[m], x[m], y[m], z[m]);
       if (pos_ok(g, x[m], y[m], z[m])) {
         const int t = tile_of_wrapped(tp, wrap_cell(home_cell_i(hc, x[m]), g.n), wrap_cell(home_cell_i(hc, y[m]), g.n),
                                       wrap_cell(home_cell_i(hc, z[m]), g.n));
@@ -241,8 +275,21 @@ k_bin_direct(Geo g, PosPar pp, SphPar sp, TilePar tp, int nsuper, const T *__res
       }
     }
     __syncthreads();
-    for (int s = threadIdx.x; s < kSlots; s += blockDim.x)
-      if (hkey[s]) hbase[s] = atomicAdd(&cnt[hkey[s] - 1], hcnt[s]);
+    {
+      // the returning atomics of a thread's occupied counters are all in flight before the first result is used
+      constexpr int kPer = kSlots / BCHMC_BIN_THREADS;
+      int hk[kPer], hb[kPer];
+#pragma unroll
+      for (int u = 0; u < kPer; u++) {
+        const int s = (int)threadIdx.x + u * BCHMC_BIN_THREADS;
+        hk[u] = hkey[s];
+        hb[u] = 0;
+        if (hk[u]) hb[u] = atomicAdd(&cnt[hk[u] - 1], hcnt[s]);
+      }
+#pragma unroll
+      for (int u = 0; u < kPer; u++)
+        if (hk[u]) hbase[(int)threadIdx.x + u * BCHMC_BIN_THREADS] = hb[u];
+    }
     __syncthreads();
     const int seg = tp.cap / kOct;
 #pragma unroll
