@@ -101,7 +101,14 @@ struct bchmc_handle {
   hipEvent_t stg_ev[2] = {nullptr, nullptr};
   size_t stg_chunk = 0;
   int stg_threads = 1;
-  hipStream_t copy_stream = nullptr;  // uploads that run beside compute (the momenta of a host-array trajectory)
+  hipStream_t copy_stream = nullptr;  // transfers that run beside compute (host-array trajectories: the momenta on their
+                                      // way in beside the start-state force, the final q on its way out beside the last one)
+  // Early download of a host-array trajectory's q1: the last step only kicks p, so the final q exists one force
+  // evaluation before the trajectory ends.  Armed by the host entry points (early_q_dev = where its real-space copy
+  // goes); trajectory_fused transforms it there before the last force evaluation and records ev_q; early_q_done says so.
+  double *early_q_dev = nullptr;
+  bool early_q_done = false;
+  hipEvent_t ev_q = nullptr;
 
   int4 *hull = nullptr;
   int hull_n = 0;
@@ -646,10 +653,14 @@ int h2d(bchmc_handle *h, void *dst, const void *src, size_t bytes, hipStream_t s
 }
 
 // device -> host after everything enqueued so far on the handle's stream; returns when `dst` is complete
-int d2h(bchmc_handle *h, void *dst, const void *src, size_t bytes) {
+// (stream: the transfers go there instead, after `after` has happened -- the early download of q1)
+int d2h(bchmc_handle *h, void *dst, const void *src, size_t bytes, hipStream_t stream = nullptr,
+        hipEvent_t after = nullptr) {
+  if (!stream) stream = h->stream;
+  if (after) HIPCHK(hipStreamWaitEvent(stream, after, 0));
   if (bytes <= ((size_t)1 << 20)) {
-    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
     return BCHMC_OK;
   }
   CHK(stg_init(h));
@@ -659,8 +670,8 @@ int d2h(bchmc_handle *h, void *dst, const void *src, size_t bytes) {
     const int b = (int)(c & 1);
     if (c < nch) {
       const size_t off = c * chunk, len = std::min(chunk, bytes - off);
-      HIPCHK(hipMemcpyAsync(h->stg[b], (const char *)src + off, len, hipMemcpyDeviceToHost, h->stream));
-      HIPCHK(hipEventRecord(h->stg_ev[b], h->stream));
+      HIPCHK(hipMemcpyAsync(h->stg[b], (const char *)src + off, len, hipMemcpyDeviceToHost, stream));
+      HIPCHK(hipEventRecord(h->stg_ev[b], stream));
     }
     if (c >= 1) {
       const size_t off = (c - 1) * chunk, len = std::min(chunk, bytes - off);
@@ -1445,6 +1456,14 @@ struct Pipe {
     }
     for (uint64_t s = 0; s < neps; s++) {
       const bool last = (s + 1 == neps);
+      if (last && h->early_q_dev && h->ev_q) {
+        // the last boundary only kicks p: this is the final q (unless the runaway guard stops the trajectory, which the
+        // caller checks).  Its real-space copy is made now, so that its transfer to the host runs beside the force
+        // evaluation that follows.
+        CHK(c2r_state(h, cur ? q1 : q0, h->ioq, h->early_q_dev));
+        HIPCHK(hipEventRecord(h->ev_q, h->stream));
+        h->early_q_done = true;
+      }
       if (h->slot_watch && h->tiled && h->sort_direct && s > 0 && s % kSlotPoll == 0 && !env_on("BCHMC_NO_SLOT_POLL"))
         CHK(poll_slots(h, s / kSlotPoll));
       h->planes_c2r = planes && (s > 0 || ends);  // Psi^ left by k_step_boundary_x still needs only the (y, z) passes
@@ -1504,10 +1523,12 @@ struct Pipe {
     if (!prologue_done) CHK(r2c_state(h, d_q0, h->ioq, h->qk));
     CHK(r2c_state(h, d_p0, h->iop, h->pk));
     CHK(trajectory(h, eps, neps, nullptr, prologue_done ? h->gk : nullptr));
-    CHK(c2r_state(h, h->qk, h->ioq, d_q1));
+    if (!h->early_q_done) CHK(c2r_state(h, h->qk, h->ioq, d_q1));  // else: made before the last force evaluation
     CHK(c2r_state(h, h->pk, h->iop, d_p1));
     return BCHMC_OK;
   }
+  // the runaway guard stopped a trajectory whose q had been sent early: transform the state it stopped in
+  static int requeue_q(bchmc_handle *h, double *d_q1) { return c2r_state(h, h->qk, h->ioq, d_q1); }
 
   // ---- device-resident chain --------------------------------------------------------------------------------
   static int chain_alloc(bchmc_handle *h) {
@@ -1564,7 +1585,8 @@ struct Pipe {
   // part6's third slot (host_prologue evaluated them while the momenta were still on their way).
   static int attempt_core(bchmc_handle *h, double eps, uint64_t neps, const double *d_q0, const double *d_p0,
                           const void *src_qk, const void *src_pk, double terms[6], uint64_t *steps_done,
-                          const void *g0_in = nullptr, double like0 = 0., void *g0_out = nullptr, bool g0_ready = false) {
+                          const void *g0_in = nullptr, double like0 = 0., void *g0_out = nullptr, bool g0_ready = false,
+                          double *host_q1 = nullptr) {
     CHK(check_inputs(h));
     if (eps > 2.) eps = 2.;
     const size_t cbytes = 2 * (size_t)h->g.Nhp * sizeof(T);
@@ -1592,6 +1614,15 @@ struct Pipe {
       k_parseval<T><<<kRedBlocks, 256, 0, h->stream>>>(h->g, C(h->pk), h->wM, P + 3 * kRedBlocks);
       k_parseval<T><<<kRedBlocks, 256, 0, h->stream>>>(h->g, C(h->qk), h->wS, P + 4 * kRedBlocks);
       HIPCHK(hipGetLastError());
+      if (host_q1) {
+        // host-array trajectory: the proposal's real-space copies go to dstage (q, unless the trajectory made it
+        // early) and dstage + N (p); everything is enqueued before this thread starts moving q1 across PCIe
+        if (!h->early_q_done) CHK(c2r_state(h, h->qk, h->ioq, h->dstage));
+        CHK(c2r_state(h, h->pk, h->iop, h->dstage + h->g.N));
+      }
+      // (before the copy of the partials below: a device-to-host copy into pageable memory returns when it is done)
+      if (host_q1 && h->early_q_done)
+        CHK(d2h(h, host_q1, h->dstage, (size_t)h->g.N * sizeof(double), h->copy_stream, h->ev_q));
       std::vector<double> hp(6 * kRedBlocks);
       unsigned long long sd = 0;
       HIPCHK(hipMemcpyAsync(hp.data(), P, hp.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -1604,6 +1635,10 @@ struct Pipe {
       }
       if (g0_in && !g0_ready) terms[2] = like0;
       if (done < neps) {
+        if (host_q1 && h->early_q_done) {  // ... and the q sent early is not the state the trajectory stopped in
+          h->early_q_done = false;
+          CHK(c2r_state(h, h->qk, h->ioq, h->dstage));
+        }
         // runaway guard fired (HMC.cc:360-364): the tapped forward model is not the final state's; redo it
         CHK(displacement(h, h->c.likelihood == 1 ? h->c.deltaQ_factor : 1., h->c.likelihood == 1 ? h->c.rsd_model : 0));
         CHK(forward_rest(h, h->c.likelihood == 1 ? h->c.rsd_model : 0));
@@ -1656,16 +1691,16 @@ struct Pipe {
   // energies of both ends come with it (bchmc_leapfrog_dh hands them to the caller, who asks for them next,
   // HMC.cc:455-459).  Leaves (q1, p1) in dstage, dstage + N.
   // prologue_done: host_prologue has run (FFT[q0] is in qk, gk and the -log L partials are the start state's).
+  // host_q1: the caller's q1 array.  With the early download armed (early_q_dev) it is filled here, beside the last
+  // force evaluation, and h->early_q_done stays set; otherwise the caller copies it from dstage as before.
   static int leapfrog_host_core(bchmc_handle *h, double eps, uint64_t neps, double terms[6], uint64_t *steps_done,
-                                bool prologue_done = false) {
+                                bool prologue_done, double *host_q1) {
     double *dq = h->dstage, *dp = h->dstage + h->g.N;
     if (attempt_is_fast(h, neps)) {
       if (!prologue_done) CHK(r2c_state(h, dq, h->ioq, h->qk));
       CHK(r2c_state(h, dp, h->iop, h->pk));
       CHK(attempt_core(h, eps, neps, nullptr, nullptr, nullptr, nullptr, terms, steps_done, nullptr, 0., nullptr,
-                       prologue_done));
-      CHK(c2r_state(h, h->qk, h->ioq, dq));
-      CHK(c2r_state(h, h->pk, h->iop, dp));
+                       prologue_done, host_q1));
     } else {
       // generic mode: energies_core transforms the staged arrays itself (it only reads dstage), and after the
       // trajectory attempt_core leaves the proposal's real-space copy there
@@ -2242,6 +2277,7 @@ void bchmc_destroy(bchmc_handle *h) {
     if (h->in_arr[f]) (void)hipFree(h->in_arr[f]);
   if (h->h_part) (void)hipHostFree(h->h_part);
   if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
+  if (h->ev_q) (void)hipEventDestroy(h->ev_q);
   if (h->h_slots) (void)hipHostFree(h->h_slots);
   for (hipEvent_t e : h->slot_ev)
     if (e) (void)hipEventDestroy(e);
@@ -2296,6 +2332,25 @@ int bchmc_steps_done(bchmc_handle *h, uint64_t *steps_done) {
   return BCHMC_OK;
 }
 
+// Arms the early download of q1 for the duration of one host-array trajectory (BCHMC_NO_DOWNLOAD_OVERLAP=1: never).
+struct EarlyQ {
+  bchmc_handle *h;
+  EarlyQ(bchmc_handle *h_, double *dev) : h(h_) {
+    h->early_q_done = false;
+    h->early_q_dev = nullptr;
+    if (!dev || !h->copy_stream || env_on("BCHMC_NO_DOWNLOAD_OVERLAP")) return;
+    if (!h->ev_q && hipEventCreateWithFlags(&h->ev_q, hipEventDisableTiming) != hipSuccess) {
+      h->ev_q = nullptr;
+      return;
+    }
+    h->early_q_dev = dev;
+  }
+  ~EarlyQ() {
+    h->early_q_dev = nullptr;
+    h->early_q_done = false;
+  }
+};
+
 int bchmc_leapfrog(bchmc_handle *h, const double *q0, const double *p0, double *q1, double *p1, double eps,
                    uint64_t neps, uint64_t *steps_done) {
   if (!h || !q0 || !p0 || !q1 || !p1) return BCHMC_ERR_ARG;
@@ -2314,11 +2369,17 @@ int bchmc_leapfrog(bchmc_handle *h, const double *q0, const double *p0, double *
   } else {
     CHK(h2d(h, dp, p0, bytes));
   }
+  EarlyQ early(h, prologue ? dq : nullptr);
   CHK(DISPATCH(h, leapfrog_core(h, dq, dp, dq, dp, eps, neps, prologue)));
-  CHK(d2h(h, q1, dq, bytes));
+  const bool sent = h->early_q_done;
+  CHK(sent ? d2h(h, q1, dq, bytes, h->copy_stream, h->ev_q) : d2h(h, q1, dq, bytes));
   CHK(d2h(h, p1, dp, bytes));
   uint64_t done = 0;
   CHK(bchmc_steps_done(h, &done));
+  if (sent && done < neps) {  // runaway guard: the q sent early is not the state the trajectory stopped in
+    CHK(DISPATCH(h, requeue_q(h, dq)));
+    CHK(d2h(h, q1, dq, bytes));
+  }
   if (steps_done) *steps_done = done;
   return BCHMC_OK;
 }
@@ -2347,8 +2408,9 @@ int bchmc_leapfrog_dh(bchmc_handle *h, const double *q0, const double *p0, doubl
   // one pass: the trajectory's own first and last force evaluation carry -log L of both ends, K and psi_prior are
   // Parseval sums of the k-space state (the resident chain's attempt_core); generic configurations evaluate the
   // energies around the trajectory without further transfers
-  CHK(DISPATCH(h, leapfrog_host_core(h, eps, neps, terms, &done, prologue)));
-  CHK(d2h(h, q1, dq, bytes));
+  EarlyQ early(h, prologue ? dq : nullptr);
+  CHK(DISPATCH(h, leapfrog_host_core(h, eps, neps, terms, &done, prologue, q1)));
+  if (!h->early_q_done) CHK(d2h(h, q1, dq, bytes));  // else: q1 crossed PCIe beside the last force evaluation
   CHK(d2h(h, p1, dp, bytes));
   if (steps_done) *steps_done = done;
   const double Hami = terms[0] + (terms[1] + terms[2]);

@@ -71,7 +71,28 @@ t3 = time.perf_counter()
 for _ in range(reps):
     host_path(False)
 t4 = time.perf_counter()
+del os.environ["BCHMC_NO_FORCE_CARRY"]
+
+
+def timed_host(**env):
+    os.environ.update(env)
+    host_path()
+    ta = time.perf_counter()
+    for _ in range(reps):
+        host_path()
+    tb = time.perf_counter()
+    for k in env:
+        del os.environ[k]
+    return 1e3 * (tb - ta) / reps
+
+
+# the two transfers that run beside compute, switched off one at a time on the same box (read per call)
+no_down = timed_host(BCHMC_NO_DOWNLOAD_OVERLAP="1")
+no_both = timed_host(BCHMC_NO_DOWNLOAD_OVERLAP="1", BCHMC_NO_UPLOAD_OVERLAP="1")
+again = timed_host()
 print(json.dumps(dict(grid=nx, neps=neps, host_array_ms_per_attempt=1e3 * (t1 - t0) / reps,
+                      host_array_again_ms=again, host_array_without_download_overlap_ms=no_down,
+                      host_array_without_either_overlap_ms=no_both,
                       resident_chain_ms_per_attempt=1e3 * (t2 - t1) / reps,
                       resident_chain_all_accepted_ms=1e3 * (t2a - t2) / reps,
                       resident_chain_gradient_recomputed_ms=1e3 * (t2c - t2b) / reps,

@@ -42,6 +42,38 @@ def test_leapfrog_dh_is_leapfrog_plus_delta_hamiltonian(kw):
     e.close()
 
 
+@pytest.mark.parametrize("nx", [16, 64])
+def test_q1_crosses_pcie_beside_the_last_force_evaluation(monkeypatch, nx):
+    """The last leapfrog step only kicks p (HMC.cc:343-352), so a host-array trajectory transforms its final q before
+    the last force evaluation and downloads it on the copy stream while that runs.  Same arrays as with
+    BCHMC_NO_DOWNLOAD_OVERLAP=1 (to the scatter's atomic-order noise) for the one-pass and the plain entry point, one
+    and several steps, several staging chunks -- and for a trajectory the runaway guard stops, where the q sent early
+    is NOT the state returned (HMC.cc:360-364) and has to be replaced."""
+    c = Case(Nx=nx, likelihood=1, rsd_model=1)
+    monkeypatch.setenv("BCHMC_STAGE_MB", "1")   # 64^3: two chunks per array
+    p_bad = c.p0.copy().ravel()
+    p_bad[0] = 1e60
+    outs = []
+    for off in ("0", "1"):
+        monkeypatch.setenv("BCHMC_NO_DOWNLOAD_OVERLAP", off)
+        e = c.engine()
+        r = [e.leapfrog_dh(c.q0, c.p0, c.eps, 3)[:3], e.leapfrog_dh(c.q0, c.p0, c.eps, 1)[:3],
+             e.leapfrog(c.q0, c.p0, c.eps, 4), e.leapfrog(c.q0, c.p0, c.eps, 1),
+             e.leapfrog_dh(c.q0, p_bad, 1e-6, 4)[:3], e.leapfrog(c.q0, p_bad, 1e-6, 4),
+             e.leapfrog_dh(c.q0, c.p0, c.eps, 2)[:3]]   # and a normal one after the stopped ones
+        outs.append(r)
+        e.close()
+    for (qa, pa, da), (qb, pb, db) in zip(*outs):
+        assert da == db
+        assert rel_l2(qa, qb) < 1e-13 and rel_l2(pa, pb) < 1e-13
+    assert outs[0][4][2] == outs[0][5][2] == 1
+    if nx == 16:
+        q1o, p1o, done_o = c.oracle.Hamiltonian_EoM(c.q0, p_bad, 1e-6, 4)
+        assert done_o == 1
+        for k in (4, 5):
+            assert rel_l2(outs[0][k][0], q1o) < 1e-10 and rel_l2(outs[0][k][1], p1o) < 1e-10
+
+
 def test_delta_hamiltonian_never_answers_from_an_earlier_call():
     """VERDICT r2 / ADVICE r2: the C ABI keeps no energy cache.  Whatever happened before, bchmc_delta_hamiltonian
     evaluates the arrays it is given against the inputs uploaded now."""
