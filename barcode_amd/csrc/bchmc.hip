@@ -1412,6 +1412,30 @@ struct Pipe {
     kern<<<grid, NT, lds, h->stream>>>(h->g, h->log2n, tw, C(h->Ck), qi, pi, qo, po, h->wS, wM, a, b, half_eps,  \
                                        eps, c_za, guard_slot, ctl, g_in, g_out);                                   \
   } while (0)
+    // interior Zel'dovich boundary with fp32 fields: the two-tile formulation (k_step_boundary_x2).  A 1024-thread
+    // workgroup is alone on its CU there and the first formulation leaves its memory phases exposed: 0.283 -> 0.231 ms
+    // at 256^3.  With fp64 fields (two 512-thread workgroups per CU) both formulations take the same 0.329 ms --
+    // 4.7 TB/s is what this access pattern (128-byte segments, one per DRAM row) gets however much is in flight -- and
+    // the first one stays (BCHMC_BX_V2=1 selects the second for fp64 too; profiles/r03_ab_bx2.txt).
+    const bool want_x2 = (sizeof(T) == 4 && !env_on("BCHMC_BX_V1")) || (sizeof(T) == 8 && n <= 256 && env_on("BCHMC_BX_V2"));
+    if (MODE == BX_INTERIOR && !ALPT && (n == 128 || n == 256) && want_x2 &&  // (512^3 fp32: no difference, v1 stays)
+        (unsigned long long)h->g.Nhp * sizeof(CT) < (1ull << 32)) {  // its lane offsets are 32-bit byte offsets
+      const size_t lds2 = ((size_t)2 * n * KB + n / 2) * sizeof(CT);
+#define BCHMC_LAUNCH_X2(NT, PER)                                                                                   \
+  do {                                                                                                             \
+    auto kern = k_step_boundary_x2<T, NT, PER>;                                                                    \
+    if (lds2 > 48 * 1024)                                                                                          \
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                 (int)lds2));                                                                      \
+    kern<<<grid, NT, lds2, h->stream>>>(h->g, h->log2n, tw, C(h->Ck), qi, pi, qo, po, h->wS, wM, a, b, half_eps, \
+                                        eps, c_za, guard_slot, ctl);                                               \
+  } while (0)
+      if (n == 128) BCHMC_LAUNCH_X2(NT_BIG, 4);
+      else BCHMC_LAUNCH_X2(2 * NT_BIG, 4);
+#undef BCHMC_LAUNCH_X2
+      HIPCHK(hipGetLastError());
+      return BCHMC_OK;
+    }
     switch (n) {
       case 32: BCHMC_LAUNCH_X(NT_SMALL, 4); break;
       case 64: BCHMC_LAUNCH_X(NT_SMALL, 8); break;

@@ -56,6 +56,31 @@ def test_other_models_at_64_cubed_against_oracle(kw):
     e.close()
 
 
+@pytest.mark.parametrize("precision", [0, 1], ids=["fp64", "fp32"])
+def test_two_tile_step_boundary_at_128_cubed(monkeypatch, precision):
+    """k_step_boundary_x2 -- both forward and both inverse x transforms at once on two LDS tiles, every operand of a
+    phase requested before the previous phase's transforms run; the default for fp32 fields at 128^3 / 256^3,
+    BCHMC_BX_V2=1 for fp64 -- against the one-tile kernel (BCHMC_BX_V1=1) and the 3-D-plan path (BCHMC_NO_PLANES=1):
+    a 6-step trajectory (five interior boundaries) at the grid size whose instantiation (256 / 512 threads, 4 elements
+    per thread, odd log2 n) the benchmark grids share."""
+    c = Case(Nx=128, L=200.0, likelihood=1, rsd_model=1)
+    c.oracle.close()
+    outs = []
+    for env in (dict(BCHMC_BX_V1="1"), dict(BCHMC_BX_V2="1"), dict(BCHMC_NO_PLANES="1")):
+        for k in ("BCHMC_BX_V1", "BCHMC_BX_V2", "BCHMC_NO_PLANES"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        e = c.engine(precision=precision)
+        q1, p1, done = e.leapfrog(c.q0, c.p0, c.eps, 6)
+        assert done == 6
+        outs.append((q1, p1))
+        e.close()
+    noise = 1e-13 if precision == 0 else 1e-5
+    for q1, p1 in outs[1:]:
+        assert rel_l2(q1, outs[0][0]) < noise and rel_l2(p1, outs[0][1]) < noise
+
+
 def test_config2_128cubed_poisson_fifty_steps_against_oracle():
     """BASELINE config 2 at its real length: 128^3, Gaussian prior + Zel'dovich, Poissonian likelihood, 50 leapfrog
     steps, fp64 (HMC.cc:251-369).  Tolerance re-stated for 50 steps: TOL_TRAJ_50 (see tests/util.py: the measured
