@@ -134,6 +134,7 @@ struct bchmc_handle {
   unsigned *stage_tab = nullptr;  // k_stage_combine81's (neighbour, own cell, image cell) table, kStageCells entries
   double *stage = nullptr;  // staging area of the scatter's LDS images, one 12 x 12 x 20 image per (tile, chunk) work item
   bool rho_unread = false;  // set around an interior step's force evaluation: the combine pass need not store rho
+  bool psi_unread = false;  // ... and nobody reads its displacements / positions: the z pass may end in the binning
   bool staged = false;      // the images of the last scatter have not been summed into rho yet (k_stage_combine81)
   TilePar tp{};
   int *t_cnt = nullptr, *t_woff = nullptr;   // 9 ntiles + 2 (one-pass counts per (tile, octant), fallback counts per tile,
@@ -885,16 +886,35 @@ struct Pipe {
     return BCHMC_OK;
   }
 
+  // the fused z pass + binning exists for the benchmark grid (one lattice site along z per thread of k_zbin_direct)
+  static bool zbin_ok(const bchmc_handle *h) {
+    return h->g.n == 256 && h->tiled && h->sort_direct && h->planes_ok && h->xtw && h->c.mk == 3 && h->c.calc_h == 2 &&
+           !env_on("BCHMC_NO_ZBIN");  // (mk 3 + calc_h 2 on tiles: nothing but the fallback sort reads Psi after the binning)
+  }
+
   // C2R of the three displacement components, mass assignment, sum of rho.  Lag2Eul.cc:90-131 / 363-423.
   // defer_combine: the caller (like_force) sums the staged density images itself, fused with the likelihood partial
   static int forward_rest(bchmc_handle *h, int rsd, bool defer_combine = false) {
     const bool stage = h->stage && h->std81 && !h->fix && h->c.mk == 3 && h->tiled;
     h->staged = false;
     if (rsd && !h->c.planepar) return h->fail(BCHMC_ERR_RSD_NOT_PLANEPAR, "non-plane-parallel RSD is not implemented");
+    bool zbin = false;
     {
       const bool planes = h->planes_c2r || h->planes_c2r_once;
       h->planes_c2r_once = false;
-      CHK(fft_exec(h, planes ? h->c2r2d : h->c2r3, h->Ck, h->psi, BCHMC_K_FFT_C2R));
+      // Interior steps of a trajectory at 256^3 (nobody reads Psi or the positions of such a step): the engine's own y
+      // pass, and the z pass inside the binning kernel below -- Psi does not go through HBM (zpass.hpp).
+      zbin = planes && h->psi_unread && zbin_ok(h);
+      if (zbin) {
+        ProfScope ps(h, BCHMC_K_FFT_C2R);
+        constexpr int KB = 128 / (int)sizeof(CT), NT = 512, PER = 256 * KB / NT;
+        const size_t lds = ((size_t)h->g.n * KB + h->g.n / 2) * sizeof(CT);
+        k_ypass<T, NT, PER, BCHMC_YPASS_NT != 0><<<3 * h->g.n * (h->g.nhp / KB), NT, lds, h->stream>>>(
+            h->g, h->log2n, reinterpret_cast<const CT *>(h->xtw), C(h->Ck));
+        HIPCHK(hipGetLastError());
+      } else {
+        CHK(fft_exec(h, planes ? h->c2r2d : h->c2r3, h->Ck, h->psi, BCHMC_K_FFT_C2R));
+      }
     }
     h->sorted_valid = false;
     bool rho_cleared = false;  // by k_bin_direct, on its way through the lattice
@@ -912,7 +932,19 @@ struct Pipe {
       // doubled at the next trajectory start) they must still fill the chip, so the grid is capped, not tiny: with 512
       // workgroups a 512^3 step in fallback mode took 69 ms instead of 22 (and the no-op launches cost 18-20 us either way)
       const int fb_grid = h->sort_direct ? std::min(nbricks, 4096) : nbricks;
-      if (h->sort_direct) {
+      if (zbin) {
+        const int zgrid = (h->g.n / 2) * (h->g.n / 2);
+        const size_t zlds = zbin_lds<T>(h->g.n);
+        const CT *tw = reinterpret_cast<const CT *>(h->xtw);
+        k_zbin_direct<T><<<zgrid, 256, zlds, h->stream>>>(h->g, pp, sp, h->tp, h->log2n, tw, C(h->Ck), cnt1, ovf,
+                                                         (RecQuad *)h->srec, R(h->V), h->rho_part,
+                                                         (h->fix || stage) ? nullptr : R(h->rho),
+                                                         h->fix ? h->rho_fix : nullptr, nullptr);
+        // a segment overflowed: the two-pass sort below needs Psi after all (returns at once otherwise)
+        k_zbin_direct<T, true><<<zgrid, 256, zlds, h->stream>>>(h->g, pp, sp, h->tp, h->log2n, tw, C(h->Ck), cnt1, ovf,
+                                                               nullptr, nullptr, nullptr, nullptr, nullptr, R(h->psi));
+        rho_cleared = true;
+      } else if (h->sort_direct) {
         const int nsuper = (nbricks + kBinPer - 1) / kBinPer;
         k_bin_direct<T><<<nsuper, BCHMC_BIN_THREADS, 0, h->stream>>>(h->g, pp, sp, h->tp, nsuper, R(h->psi), cnt1, ovf,
                                                        (RecQuad *)h->srec, R(h->V), h->rho_part,
@@ -1495,8 +1527,10 @@ struct Pipe {
       h->alpt_pending = alpt_x;                    // ... or delta(1)^ | Phi^ planes for the ALPT pipeline
       h->rho_unread = !last && h->c.calc_h != 0 && !env_on("BCHMC_KEEP_RHO");  // rho of an interior step is read by
                                                                                    // nobody (calc_h 0: k_overdens does)
+      h->psi_unread = !last;
       const int rc = force_sources(h, true, &like_mode, &b);
       h->rho_unread = false;
+      h->psi_unread = false;
       const bool xmode = h->planes_r2c && like_mode == 0;
       h->planes_c2r = h->planes_r2c = false;
       CHK(rc);

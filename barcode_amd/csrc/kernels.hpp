@@ -23,3 +23,4 @@
 #include "spectrum.hpp"  // measure_spectrum
 #include "step_boundary_x.hpp"  // Planes mode: step boundary with the x passes of both transforms fused in
 #include "alpt_x.hpp"  // Planes mode of the ALPT displacement: mix + cell-boundary average with the x passes fused in
+#include "zpass.hpp"  // Planes mode: the y and z passes of the inverse transform by the engine, the z pass ending in the binning

@@ -193,6 +193,37 @@ def test_256_planes_mode_is_the_3d_plan_trajectory(big, monkeypatch):
     assert rel_l2(q1, q2) < 1e-13 and rel_l2(p1, p2) < 1e-12
 
 
+@pytest.mark.parametrize("precision", [0, 1], ids=["fp64", "fp32"])
+def test_256_z_pass_inside_the_binning(big, monkeypatch, precision):
+    """Interior steps at 256^3 run the engine's own y pass (k_ypass) and the z pass inside the binning kernel
+    (k_zbin_direct: two real rows per complex LDS transform, pair-wise 64-bit counter atomics) instead of rocFFT's 2-D
+    C2R + k_bin_direct.  Same trajectory as with BCHMC_NO_ZBIN=1 to the scatter's summation noise -- also when a record
+    segment overflows inside an interior step (BCHMC_SORT_CAP=4096: 512 slots per segment for populations of ~900), where
+    k_zbin_direct<PSI_ONLY> has to hand the displacements to the two-pass fallback sort; the fused kernel on the last
+    step is not used (its positions may be fetched), which the deltaX comparison checks."""
+    from barcode_amd.engine import Engine
+    p, f, _, dX = big
+    window, noise, nobs = inputs.mock_observations(p, dX)
+    eps = 0.5 * p.eps_heuristic()
+    outs = []
+    for env in (dict(BCHMC_NO_ZBIN="1"), dict(), dict(BCHMC_SORT_CAP="4096", BCHMC_SORT_CAP_FIXED="1")):
+        for k in ("BCHMC_NO_ZBIN", "BCHMC_SORT_CAP", "BCHMC_SORT_CAP_FIXED"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        e2 = Engine(p, precision=precision)
+        e2.upload(signal_PS=f["signal_PS"], mass_f=f["mass_f"], window=window, noise=noise, nobs=nobs)
+        q1, p1, done = e2.leapfrog(f["q0"], f["p0"], eps, 5)
+        assert done == 5
+        outs.append((q1, p1, e2.fetch("deltaX"), e2.fetch("posz")))
+        e2.close()
+    noise_q, noise_p = (1e-13, 1e-12) if precision == 0 else (1e-5, 1e-5)
+    for q1, p1, dx, pz in outs[1:]:
+        assert rel_l2(q1, outs[0][0]) < noise_q and rel_l2(p1, outs[0][1]) < noise_p
+        assert rel_l2(dx, outs[0][2]) < (1e-11 if precision == 0 else 1e-4)
+        assert rel_l2(pz, outs[0][3]) < (1e-13 if precision == 0 else 1e-5)
+
+
 def test_256_energy_terms_against_real_space_evaluation(big):
     """The engine evaluates 1/2 x^T A x by Parseval in k-space; compare with the reference's real-space form
     0.5 * sum(x * IFFT[w FFT x]) (HMC.cc:101-115, gaussian.cpp:24-32) computed with numpy, and the Gaussian
