@@ -886,9 +886,12 @@ struct Pipe {
     return BCHMC_OK;
   }
 
-  // the fused z pass + binning exists for the benchmark grid (one lattice site along z per thread of k_zbin_direct)
+  // the fused z pass + binning exists for the benchmark grids (one lattice site along z per thread of k_zbin_direct)
   static bool zbin_ok(const bchmc_handle *h) {
-    return h->g.n == 256 && h->tiled && h->sort_direct && h->planes_ok && h->xtw && h->c.mk == 3 && h->c.calc_h == 2 &&
+    // (128^3: measured 2 % slower -- 4096 small workgroups, the binning part grows by more than rocFFT's row pass
+    // costs there -- so rocFFT keeps it unless BCHMC_ZBIN_128=1, which the tests use for the n = 128 instantiation)
+    const bool size_ok = h->g.n == 256 || h->g.n == 512 || (h->g.n == 128 && env_on("BCHMC_ZBIN_128"));
+    return size_ok && h->tiled && h->sort_direct && h->planes_ok && h->xtw && h->c.mk == 3 && h->c.calc_h == 2 &&
            !env_on("BCHMC_NO_ZBIN");  // (mk 3 + calc_h 2 on tiles: nothing but the fallback sort reads Psi after the binning)
   }
 
@@ -902,15 +905,27 @@ struct Pipe {
     {
       const bool planes = h->planes_c2r || h->planes_c2r_once;
       h->planes_c2r_once = false;
-      // Interior steps of a trajectory at 256^3 (nobody reads Psi or the positions of such a step): the engine's own y
+      // Interior steps of a trajectory at 128^3 / 256^3 / 512^3 (nobody reads Psi or the positions of such a step): the engine's own y
       // pass, and the z pass inside the binning kernel below -- Psi does not go through HBM (zpass.hpp).
       zbin = planes && h->psi_unread && zbin_ok(h);
       if (zbin) {
         ProfScope ps(h, BCHMC_K_FFT_C2R);
-        constexpr int KB = 128 / (int)sizeof(CT), NT = 512, PER = 256 * KB / NT;
-        const size_t lds = ((size_t)h->g.n * KB + h->g.n / 2) * sizeof(CT);
-        k_ypass<T, NT, PER, BCHMC_YPASS_NT != 0><<<3 * h->g.n * (h->g.nhp / KB), NT, lds, h->stream>>>(
-            h->g, h->log2n, reinterpret_cast<const CT *>(h->xtw), C(h->Ck));
+        constexpr int KB = 128 / (int)sizeof(CT);
+        const int n = h->g.n, ygrid = 3 * n * (h->g.nhp / KB);
+        const size_t lds = ((size_t)n * KB + n / 2) * sizeof(CT);
+        const CT *tw = reinterpret_cast<const CT *>(h->xtw);
+#define BCHMC_LAUNCH_Y(NT, NN)                                                                                     \
+  do {                                                                                                             \
+    auto kern = k_ypass<T, NT, NN * KB / NT, BCHMC_YPASS_NT != 0>;                                                 \
+    if (lds > 48 * 1024)                                                                                           \
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                 (int)lds));                                                                       \
+    kern<<<ygrid, NT, lds, h->stream>>>(h->g, h->log2n, tw, C(h->Ck));                                             \
+  } while (0)
+        if (n == 128) BCHMC_LAUNCH_Y(256, 128);
+        else if (n == 256) BCHMC_LAUNCH_Y(512, 256);
+        else BCHMC_LAUNCH_Y(512, 512);
+#undef BCHMC_LAUNCH_Y
         HIPCHK(hipGetLastError());
       } else {
         CHK(fft_exec(h, planes ? h->c2r2d : h->c2r3, h->Ck, h->psi, BCHMC_K_FFT_C2R));
@@ -933,16 +948,30 @@ struct Pipe {
       // workgroups a 512^3 step in fallback mode took 69 ms instead of 22 (and the no-op launches cost 18-20 us either way)
       const int fb_grid = h->sort_direct ? std::min(nbricks, 4096) : nbricks;
       if (zbin) {
-        const int zgrid = (h->g.n / 2) * (h->g.n / 2);
-        const size_t zlds = zbin_lds<T>(h->g.n);
+        const int n = h->g.n, zgrid = (n / 2) * (n / 2);
+        const size_t zlds = zbin_lds<T>(n);
         const CT *tw = reinterpret_cast<const CT *>(h->xtw);
-        k_zbin_direct<T><<<zgrid, 256, zlds, h->stream>>>(h->g, pp, sp, h->tp, h->log2n, tw, C(h->Ck), cnt1, ovf,
-                                                         (RecQuad *)h->srec, R(h->V), h->rho_part,
-                                                         (h->fix || stage) ? nullptr : R(h->rho),
-                                                         h->fix ? h->rho_fix : nullptr, nullptr);
-        // a segment overflowed: the two-pass sort below needs Psi after all (returns at once otherwise)
-        k_zbin_direct<T, true><<<zgrid, 256, zlds, h->stream>>>(h->g, pp, sp, h->tp, h->log2n, tw, C(h->Ck), cnt1, ovf,
-                                                               nullptr, nullptr, nullptr, nullptr, nullptr, R(h->psi));
+        // second launch: a segment overflowed -> the two-pass sort below needs Psi after all (returns at once otherwise)
+#define BCHMC_LAUNCH_Z(NZ)                                                                                          \
+  do {                                                                                                              \
+    auto kern = k_zbin_direct<T, NZ>;                                                                               \
+    auto kpsi = k_zbin_direct<T, NZ, true>;                                                                         \
+    if (zlds > 48 * 1024) {                                                                                         \
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                 (int)zlds));                                                                       \
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kpsi), hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                 (int)zlds));                                                                       \
+    }                                                                                                               \
+    kern<<<zgrid, NZ, zlds, h->stream>>>(h->g, pp, sp, h->tp, h->log2n, tw, C(h->Ck), cnt1, ovf, (RecQuad *)h->srec, \
+                                         R(h->V), h->rho_part, (h->fix || stage) ? nullptr : R(h->rho),             \
+                                         h->fix ? h->rho_fix : nullptr, nullptr);                                   \
+    kpsi<<<zgrid, NZ, zlds, h->stream>>>(h->g, pp, sp, h->tp, h->log2n, tw, C(h->Ck), cnt1, ovf, nullptr, nullptr,  \
+                                         nullptr, nullptr, nullptr, R(h->psi));                                     \
+  } while (0)
+        if (n == 128) BCHMC_LAUNCH_Z(128);
+        else if (n == 256) BCHMC_LAUNCH_Z(256);
+        else BCHMC_LAUNCH_Z(512);
+#undef BCHMC_LAUNCH_Z
         rho_cleared = true;
       } else if (h->sort_direct) {
         const int nsuper = (nbricks + kBinPer - 1) / kBinPer;

@@ -58,7 +58,7 @@ k_ypass(Geo g, int log2n, const C2<T> *__restrict__ twiddle, C2<T> *c) {
 // binning (k_bin_direct, tiles.hpp): Psi never goes to HBM between them (3 R written by rocFFT's row pass + 3 R read by
 // the binning, 0.8 GB per step at 256^3 fp64).
 //
-// One workgroup of 256 threads takes the four z rows (i0 + f, j0 + e), f, e in {0, 1}, of the 2 x 2 x n column of the
+// One workgroup of n threads takes the four z rows (i0 + f, j0 + e), f, e in {0, 1}, of the 2 x 2 x n column of the
 // Lagrangian lattice: 4 n particles.  Two real rows go through ONE complex transform: with half-complex spectra A, B
 // of the rows (i0 + f, j0) and (i0 + f, j0 + 1), Z[k] = A[k] + i B[k] for k <= n/2 and Z[n - k] = conj(A[k]) + i conj(B[k])
 // is the spectrum of a + i b, so the inverse complex transform returns row a in its real and row b in its imaginary
@@ -76,18 +76,21 @@ k_ypass(Geo g, int log2n, const C2<T> *__restrict__ twiddle, C2<T> *c) {
 // PSI_ONLY: the kernel for the rare step in which the binning overflowed -- returns at once unless *ovf is set, else
 // transforms again and stores the displacements where rocFFT's row pass would have, for the two-pass fallback sort.
 // psi_out != nullptr (binning variant): the same store on the way (force evaluations whose positions are fetched).
-// Requires n == 256 (one lattice site along z per thread).
+// Requires n == NZ (one lattice site along z per thread), n in {128, 256, 512}.
 // ======================================================================================================
-#ifndef BCHMC_ZBIN_WAVES
-#define BCHMC_ZBIN_WAVES (sizeof(T) == 8 ? 3 : 4)  // 3 / 4 / 5 waves per SIMD measured alike for fp64 (0.350 / 0.353 / 0.344 ms)
+#ifndef BCHMC_ZBIN_WAVES  // 3 / 4 / 5 waves per SIMD measured alike for fp64 at 256^3 (0.350 / 0.353 / 0.344 ms); a 512-thread
+#define BCHMC_ZBIN_WAVES ((sizeof(T) == 8 && NZ < 512) ? 3 : 4)  // workgroup needs 4 for two workgroups per CU
 #endif
-template <typename T, bool PSI_ONLY = false, int EXPT = 0>  // EXPT != 0: timing experiments of scripts/zpass_bench.hip
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BCHMC_ZBIN_WAVES, BCHMC_ZBIN_WAVES)))
+// NZ = n = threads per workgroup (one lattice site along z per thread): 128, 256 or 512
+template <typename T, int NZ, bool PSI_ONLY = false, int EXPT = 0>  // EXPT != 0: timing experiments of scripts/zpass_bench.hip
+__global__ void __launch_bounds__(NZ) __attribute__((amdgpu_waves_per_eu(BCHMC_ZBIN_WAVES, BCHMC_ZBIN_WAVES)))
 k_zbin_direct(Geo g, PosPar pp, SphPar sp, TilePar tp, int log2n, const C2<T> *__restrict__ twiddle,
               const C2<T> *__restrict__ ck, int *__restrict__ cnt, int *__restrict__ ovf, RecQuad *__restrict__ srec,
               T *__restrict__ V, double *__restrict__ zero_part, T *__restrict__ rho_zero,
               long long *__restrict__ fix_zero, T *__restrict__ psi_out) {
-  constexpr int kSlots = 1024;  // = particles per workgroup: more distinct counters cannot occur, the probing terminates
+  constexpr int kSlots = 4 * NZ;  // = particles per workgroup: more distinct counters cannot occur, the probing terminates
+  constexpr int kHashShift = 32 - (NZ == 128 ? 9 : (NZ == 256 ? 10 : 11));
+  static_assert(NZ == 128 || NZ == 256 || NZ == 512, "k_zbin_direct: one thread per lattice site along z");
   constexpr int KF = 6;         // interleaved transforms: (component, row pair)
   // One LDS area, used twice: the transform tile + twiddles ((6 n + n / 2) complex), then -- after every thread has
   // taken its displacements out of it -- the hash table of the binning (20 KB).  zbin_lds() is its size.
@@ -100,8 +103,8 @@ k_zbin_direct(Geo g, PosPar pp, SphPar sp, TilePar tp, int log2n, const C2<T> *_
   C2<T> *s = reinterpret_cast<C2<T> *>(s_raw_z);  // n * KF
   C2<T> *tw = s + (size_t)n * KF;                 // n / 2
   if (!PSI_ONLY && zero_part && blockIdx.x == 0)
-    for (int i = tid; i < kRedBlocks; i += 256) zero_part[i] = 0.;
-  for (int t = tid; t < n / 2; t += 256) tw[t] = twiddle[t];
+    for (int i = tid; i < kRedBlocks; i += NZ) zero_part[i] = 0.;
+  for (int t = tid; t < n / 2; t += NZ) tw[t] = twiddle[t];
   const int nb = n >> 1;
   int j0 = 2 * ((int)blockIdx.x % nb), i0 = 2 * ((int)blockIdx.x / nb);
   if (EXPT == 8) j0 = 2 * ((((int)blockIdx.x % nb) * 17) % nb);
@@ -111,10 +114,11 @@ k_zbin_direct(Geo g, PosPar pp, SphPar sp, TilePar tp, int log2n, const C2<T> *_
   }
   const int shift = 32 - log2n;
   {
-    // fill: wave w takes pair f = w & 1 and the wavenumbers kk = 64 (w >> 1) + lane  (n = 256: kk < 128 = n / 2)
+    // fill: wave w takes pair f = w & 1 and the wavenumbers kk = 64 (w >> 1) + lane: the n / 64 waves cover kk < n / 2
     const int w = tid >> 6, f = w & 1;
     const long long row = (long long)g.nhp * (j0 + (long long)n * (i0 + f));  // element (i0 + f, j0, 0)
-    for (int kk = ((w >> 1) << 6) + (tid & 63); kk < n / 2; kk += (256 >> 1)) {
+    {
+      const int kk = ((w >> 1) << 6) + (tid & 63);
       C2<T> a[3], b[3], an[3], bn[3];
 #pragma unroll
       for (int c = 0; c < 3; c++) {
@@ -159,7 +163,7 @@ k_zbin_direct(Geo g, PosPar pp, SphPar sp, TilePar tp, int log2n, const C2<T> *_
   }
   if (!PSI_ONLY) {
     __syncthreads();  // the tile is free: it becomes the hash table
-    for (int t = tid; t < kSlots; t += 256) {
+    for (int t = tid; t < kSlots; t += NZ) {
       hkey[t] = 0;
       hcnt[t] = 0ull;
     }
@@ -186,7 +190,7 @@ k_zbin_direct(Geo g, PosPar pp, SphPar sp, TilePar tp, int log2n, const C2<T> *_
       flag[m] = in_domain(g, sp, x[m], y[m], z[m]) ? 0 : kSortFlagNoScatter;
       key[m] = t * kOct + subcell_octant<T>(x[m], y[m], z[m], hc.inv_d);
       const int pk = key[m] >> 1;  // the pair of counters (2 pk, 2 pk + 1)
-      int sl = (int)(((unsigned)pk * 2654435761u) >> 22) & (kSlots - 1);
+      int sl = (int)(((unsigned)pk * 2654435761u) >> kHashShift) & (kSlots - 1);
       for (;;) {
         const int old = atomicCAS(&hkey[sl], 0, pk + 1);
         if (old == 0 || old == pk + 1) break;
@@ -204,12 +208,12 @@ k_zbin_direct(Geo g, PosPar pp, SphPar sp, TilePar tp, int log2n, const C2<T> *_
   if (PSI_ONLY) return;
   __syncthreads();
   {
-    constexpr int kPer = kSlots / 256;
+    constexpr int kPer = kSlots / NZ;
     int hk[kPer];
     unsigned long long hb[kPer];
 #pragma unroll
     for (int u = 0; u < kPer; u++) {
-      const int sl = tid + u * 256;
+      const int sl = tid + u * NZ;
       hk[u] = hkey[sl];
       hb[u] = 0ull;
       if (hk[u] && EXPT != 4)
@@ -217,7 +221,7 @@ k_zbin_direct(Geo g, PosPar pp, SphPar sp, TilePar tp, int log2n, const C2<T> *_
     }
 #pragma unroll
     for (int u = 0; u < kPer; u++)
-      if (hk[u]) hbase[tid + u * 256] = hb[u];
+      if (hk[u]) hbase[tid + u * NZ] = hb[u];
   }
   __syncthreads();
   const int seg = tp.cap / kOct;
@@ -240,7 +244,7 @@ k_zbin_direct(Geo g, PosPar pp, SphPar sp, TilePar tp, int log2n, const C2<T> *_
 
 // dynamic LDS of k_zbin_direct
 template <typename T> inline size_t zbin_lds(int n) {
-  const size_t tile = ((size_t)n * 6 + n / 2) * sizeof(C2<T>), hash = (size_t)1024 * 20;
+  const size_t tile = ((size_t)n * 6 + n / 2) * sizeof(C2<T>), hash = (size_t)4 * n * 20;
   return tile > hash ? tile : hash;
 }
 

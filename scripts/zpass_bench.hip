@@ -168,7 +168,7 @@ int main(int argc, char **argv) {
   const int nsuper = (n / 4) * (n / 4) * (n / 16) / 4;
   const size_t ldsz = zbin_lds<double>(n);
   k_bin_direct<double><<<nsuper, 256>>>(g, pp, sp, tp, nsuper, d_psi, d_cnt, d_ovf, d_rec, d_V, d_zero, d_rho, nullptr);
-  k_zbin_direct<double><<<(n / 2) * (n / 2), 256, ldsz>>>(g, pp, sp, tp, log2n, d_tw, d_c, d_cnt2, d_ovf, d_rec, d_V, d_zero,
+  k_zbin_direct<double, 256><<<(n / 2) * (n / 2), 256, ldsz>>>(g, pp, sp, tp, log2n, d_tw, d_c, d_cnt2, d_ovf, d_rec, d_V, d_zero,
                                                          d_rho, nullptr, d_psi2);
   CK(hipGetLastError());
   CK(hipDeviceSynchronize());
@@ -201,13 +201,13 @@ int main(int argc, char **argv) {
     }, 0);
     time_it("k_zbin_direct<double> (z pass + binning)", [&] {
       clear();
-      k_zbin_direct<double><<<(n / 2) * (n / 2), 256, ldsz>>>(g, pp, sp, tp, log2n, d_tw, d_c, d_cnt, d_ovf, d_rec, d_V,
+      k_zbin_direct<double, 256><<<(n / 2) * (n / 2), 256, ldsz>>>(g, pp, sp, tp, log2n, d_tw, d_c, d_cnt, d_ovf, d_rec, d_V,
                                                              d_zero, d_rho, nullptr, nullptr);
     }, 0);
 #define ZEX(E, what)                                                                                                  \
   time_it(what, [&] {                                                                                                 \
     clear();                                                                                                          \
-    k_zbin_direct<double, false, E><<<(n / 2) * (n / 2), 256, ldsz>>>(g, pp, sp, tp, log2n, d_tw, d_c, d_cnt, d_ovf, d_rec, d_V, \
+    k_zbin_direct<double, 256, false, E><<<(n / 2) * (n / 2), 256, ldsz>>>(g, pp, sp, tp, log2n, d_tw, d_c, d_cnt, d_ovf, d_rec, d_V, \
                                                               d_zero, d_rho, nullptr, nullptr);                        \
   }, 0)
     ZEX(1, "  without the LDS transform");
@@ -218,7 +218,7 @@ int main(int argc, char **argv) {
     ZEX(9, "  ... and 17 apart in i in consecutive rows of workgroups");
     time_it("k_zbin_direct<double> + psi stored", [&] {
       clear();
-      k_zbin_direct<double><<<(n / 2) * (n / 2), 256, ldsz>>>(g, pp, sp, tp, log2n, d_tw, d_c, d_cnt, d_ovf, d_rec, d_V,
+      k_zbin_direct<double, 256><<<(n / 2) * (n / 2), 256, ldsz>>>(g, pp, sp, tp, log2n, d_tw, d_c, d_cnt, d_ovf, d_rec, d_V,
                                                              d_zero, d_rho, nullptr, d_psi2);
     }, 0);
   }

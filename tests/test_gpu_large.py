@@ -81,6 +81,30 @@ def test_two_tile_step_boundary_at_128_cubed(monkeypatch, precision):
         assert rel_l2(q1, outs[0][0]) < noise and rel_l2(p1, outs[0][1]) < noise
 
 
+@pytest.mark.parametrize("precision", [0, 1], ids=["fp64", "fp32"])
+def test_128_z_pass_inside_the_binning(monkeypatch, precision):
+    """k_ypass + k_zbin_direct<T, 128> (odd log2 n: a radix-2 stage first; two waves per workgroup) against rocFFT's 2-D
+    C2R + k_bin_direct (BCHMC_NO_ZBIN=1), with and without a forced overflow of the record segments; the 256^3 and
+    512^3 instantiations are covered by test_256_z_pass_inside_the_binning and the 512^3 planes-vs-3-D test."""
+    c = Case(Nx=128, L=200.0, likelihood=1, rsd_model=1)
+    c.oracle.close()
+    monkeypatch.setenv("BCHMC_ZBIN_128", "1")  # 128^3 keeps rocFFT by default (2 % faster there)
+    outs = []
+    for env in (dict(BCHMC_NO_ZBIN="1"), dict(), dict(BCHMC_SORT_CAP="2048", BCHMC_SORT_CAP_FIXED="1")):
+        for k in ("BCHMC_NO_ZBIN", "BCHMC_SORT_CAP", "BCHMC_SORT_CAP_FIXED"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        e = c.engine(precision=precision)
+        q1, p1, done = e.leapfrog(c.q0, c.p0, c.eps, 5)
+        assert done == 5
+        outs.append((q1, p1))
+        e.close()
+    noise = 1e-13 if precision == 0 else 1e-5
+    for q1, p1 in outs[1:]:
+        assert rel_l2(q1, outs[0][0]) < noise and rel_l2(p1, outs[0][1]) < 10 * noise
+
+
 def test_config2_128cubed_poisson_fifty_steps_against_oracle():
     """BASELINE config 2 at its real length: 128^3, Gaussian prior + Zel'dovich, Poissonian likelihood, 50 leapfrog
     steps, fp64 (HMC.cc:251-369).  Tolerance re-stated for 50 steps: TOL_TRAJ_50 (see tests/util.py: the measured
