@@ -248,6 +248,34 @@ def test_256_z_pass_inside_the_binning(big, monkeypatch, precision):
         assert rel_l2(pz, outs[0][3]) < (1e-13 if precision == 0 else 1e-5)
 
 
+def test_256_z_pass_inside_the_binning_alpt_and_deterministic(big, monkeypatch):
+    """The same comparison for the two other users of the planes-space C2R at 256^3: the ALPT forward model (its mix
+    kernel leaves Psi^ in planes space like the Zel'dovich boundary does) and the deterministic mode (k_zbin_direct
+    clears the fixed-point density instead of rho; results must be bit-identical to the rocFFT path's only up to the
+    transform's own rounding, so the comparison is at round-off, not exact)."""
+    from barcode_amd.engine import Engine
+    p, f, _, dX = big
+    window, noise, nobs = inputs.mock_observations(p, dX)
+    cases = [(HamilParams(Nx=256, L=200.0, likelihood=1, rsd_model=0, sfmodel=2), {}, 0.2),
+             (p, dict(BCHMC_DETERMINISTIC="1"), 0.5)]
+    for pc, extra, scale in cases:
+        eps = scale * pc.eps_heuristic()
+        outs = []
+        for nozbin in ("1", "0"):
+            monkeypatch.setenv("BCHMC_NO_ZBIN", nozbin)
+            for k, v in extra.items():
+                monkeypatch.setenv(k, v)
+            e2 = Engine(pc)
+            e2.upload(signal_PS=f["signal_PS"], mass_f=f["mass_f"], window=window, noise=noise, nobs=nobs)
+            q1, p1, done = e2.leapfrog(f["q0"], f["p0"], eps, 4)
+            assert done == 4
+            outs.append((q1, p1))
+            e2.close()
+        for k in extra:
+            monkeypatch.delenv(k, raising=False)
+        assert rel_l2(outs[1][0], outs[0][0]) < 1e-13 and rel_l2(outs[1][1], outs[0][1]) < 1e-11
+
+
 def test_256_energy_terms_against_real_space_evaluation(big):
     """The engine evaluates 1/2 x^T A x by Parseval in k-space; compare with the reference's real-space form
     0.5 * sum(x * IFFT[w FFT x]) (HMC.cc:101-115, gaussian.cpp:24-32) computed with numpy, and the Gaussian
