@@ -918,7 +918,7 @@ struct Pipe {
         const CT *tw = reinterpret_cast<const CT *>(h->xtw);
 #define BCHMC_LAUNCH_Y(NT, NN)                                                                                     \
   do {                                                                                                             \
-    auto kern = k_ypass<T, NT, NN * KB / NT, BCHMC_YPASS_NT != 0>;                                                 \
+    auto kern = k_ypass<T, NT, NN * KB / NT, BCHMC_YPASS_NT>;                                                 \
     if (lds > 48 * 1024)                                                                                           \
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                  (int)lds));                                                                       \

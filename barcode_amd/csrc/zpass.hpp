@@ -6,7 +6,10 @@
 #include "common.hpp"
 
 #ifndef BCHMC_YPASS_NT
-#define BCHMC_YPASS_NT 1  // streaming hints on k_ypass's loads and stores (scripts/zpass_bench.hip: 0.161 -> 0.142 ms)
+#define BCHMC_YPASS_NT 0  // streaming hints on k_ypass (1 loads and stores, 2 loads, 3 stores).  Alone, scripts/zpass_bench.hip,
+                          // they are worth 0.161 -> 0.142 ms on some boxes and nothing on others; in the engine the kernel that
+                          // follows re-reads what this one wrote, and without hints the y + z pair is 0.012 ms faster (C2R class
+                          // 0.189 / 0.177 / 0.176 ms with 1 / 2 / 0, same box, 3 alternations)
 #endif
 
 namespace bchmc {
@@ -19,7 +22,7 @@ namespace bchmc {
 // alone (its batch is one-dimensional; the y columns are batched over i AND k).  Unnormalised, like rocFFT.
 // Requires n a power of two with n == PER * NT / KB and nhp a multiple of KB.
 // ======================================================================================================
-template <typename T, int NT, int PER, bool HINT = false>
+template <typename T, int NT, int PER, int HINT = 0>  // streaming hints: 1 loads and stores, 2 loads only, 3 stores only
 __global__ void __launch_bounds__(NT)
 k_ypass(Geo g, int log2n, const C2<T> *__restrict__ twiddle, C2<T> *c) {
   constexpr int KB = 128 / (int)sizeof(C2<T>);
@@ -39,7 +42,8 @@ k_ypass(Geo g, int log2n, const C2<T> *__restrict__ twiddle, C2<T> *c) {
   C2<T> v[PER];
 #pragma unroll
   for (int m = 0; m < PER; m++)
-    v[m] = HINT ? bx_load(base + (long long)g.nhp * (jrow + rows * m)) : base[(long long)g.nhp * (jrow + rows * m)];
+    v[m] = (HINT == 1 || HINT == 2) ? bx_load(base + (long long)g.nhp * (jrow + rows * m))
+                                    : base[(long long)g.nhp * (jrow + rows * m)];
 #pragma unroll
   for (int m = 0; m < PER; m++) s[(int)(__brev((unsigned)(jrow + rows * m)) >> shift) * KB + col] = v[m];
   __syncthreads();
@@ -47,7 +51,7 @@ k_ypass(Geo g, int log2n, const C2<T> *__restrict__ twiddle, C2<T> *c) {
 #pragma unroll
   for (int m = 0; m < PER; m++) {
     const int j = jrow + rows * m;
-    if (HINT) bx_store(base + (long long)g.nhp * j, s[j * KB + col]);
+    if (HINT == 1 || HINT == 3) bx_store(base + (long long)g.nhp * j, s[j * KB + col]);
     else base[(long long)g.nhp * j] = s[j * KB + col];
   }
 }

@@ -86,8 +86,10 @@ int main(int argc, char **argv) {
           2.0 * 3 * Nhp * 16);
   time_it("k_ypass<double,256,8> in place, 3 components", [&] { k_ypass<double, 256, 8><<<grid, 256, lds>>>(g, log2n, d_tw, d_c); },
           2.0 * 3 * Nhp * 16);
-  time_it("k_ypass<double,512,4,nt>", [&] { k_ypass<double, 512, 4, true><<<grid, 512, lds>>>(g, log2n, d_tw, d_c); }, 2.0 * 3 * Nhp * 16);
-  time_it("k_ypass<double,256,8,nt>", [&] { k_ypass<double, 256, 8, true><<<grid, 256, lds>>>(g, log2n, d_tw, d_c); }, 2.0 * 3 * Nhp * 16);
+  time_it("k_ypass<double,512,4,nt>", [&] { k_ypass<double, 512, 4, 1><<<grid, 512, lds>>>(g, log2n, d_tw, d_c); }, 2.0 * 3 * Nhp * 16);
+  time_it("k_ypass<double,256,8,nt>", [&] { k_ypass<double, 256, 8, 1><<<grid, 256, lds>>>(g, log2n, d_tw, d_c); }, 2.0 * 3 * Nhp * 16);
+  time_it("k_ypass<double,512,4,nt loads>", [&] { k_ypass<double, 512, 4, 2><<<grid, 512, lds>>>(g, log2n, d_tw, d_c); }, 2.0 * 3 * Nhp * 16);
+  time_it("k_ypass<double,512,4,nt stores>", [&] { k_ypass<double, 512, 4, 3><<<grid, 512, lds>>>(g, log2n, d_tw, d_c); }, 2.0 * 3 * Nhp * 16);
   time_it("k_ypass<double,1024,2>", [&] { k_ypass<double, 1024, 2><<<grid, 1024, lds>>>(g, log2n, d_tw, d_c); }, 2.0 * 3 * Nhp * 16);
   time_it("k_ypass<double,128,16>", [&] { k_ypass<double, 128, 16><<<grid, 128, lds>>>(g, log2n, d_tw, d_c); }, 2.0 * 3 * Nhp * 16);
   // ---- z pass fused into the binning ----
