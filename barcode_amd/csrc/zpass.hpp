@@ -86,7 +86,7 @@ k_ypass(Geo g, int log2n, const C2<T> *__restrict__ twiddle, C2<T> *c) {
 #define BCHMC_ZBIN_WAVES ((sizeof(T) == 8 && NZ < 512) ? 3 : 4)  // workgroup needs 4 for two workgroups per CU
 #endif
 // NZ = n = threads per workgroup (one lattice site along z per thread): 128, 256 or 512
-template <typename T, int NZ, bool PSI_ONLY = false, int EXPT = 0>  // EXPT != 0: timing experiments of scripts/zpass_bench.hip
+template <typename T, int NZ, bool PSI_ONLY = false>
 __global__ void __launch_bounds__(NZ) __attribute__((amdgpu_waves_per_eu(BCHMC_ZBIN_WAVES, BCHMC_ZBIN_WAVES)))
 k_zbin_direct(Geo g, PosPar pp, SphPar sp, TilePar tp, int log2n, const C2<T> *__restrict__ twiddle,
               const C2<T> *__restrict__ ck, int *__restrict__ cnt, int *__restrict__ ovf, RecQuad *__restrict__ srec,
@@ -110,12 +110,7 @@ k_zbin_direct(Geo g, PosPar pp, SphPar sp, TilePar tp, int log2n, const C2<T> *_
     for (int i = tid; i < kRedBlocks; i += NZ) zero_part[i] = 0.;
   for (int t = tid; t < n / 2; t += NZ) tw[t] = twiddle[t];
   const int nb = n >> 1;
-  int j0 = 2 * ((int)blockIdx.x % nb), i0 = 2 * ((int)blockIdx.x / nb);
-  if (EXPT == 8) j0 = 2 * ((((int)blockIdx.x % nb) * 17) % nb);
-  if (EXPT == 9) {
-    j0 = 2 * ((((int)blockIdx.x % nb) * 17) % nb);
-    i0 = 2 * ((((int)blockIdx.x / nb) * 17) % nb);
-  }
+  const int j0 = 2 * ((int)blockIdx.x % nb), i0 = 2 * ((int)blockIdx.x / nb);
   const int shift = 32 - log2n;
   {
     // fill: wave w takes pair f = w & 1 and the wavenumbers kk = 64 (w >> 1) + lane: the n / 64 waves cover kk < n / 2
@@ -152,7 +147,7 @@ k_zbin_direct(Geo g, PosPar pp, SphPar sp, TilePar tp, int log2n, const C2<T> *_
     }
   }
   __syncthreads();
-  if (EXPT != 1) xfft_inplace<T>(s, tw, n, log2n, KF, true);
+  xfft_inplace<T>(s, tw, n, log2n, KF, true);
   // ---- thread t: the particles (i0 + f, j0 + e, k = t) ----
   const HomeCell<T> hc = make_home<T>(g);
   long long p[4];
@@ -220,7 +215,7 @@ k_zbin_direct(Geo g, PosPar pp, SphPar sp, TilePar tp, int log2n, const C2<T> *_
       const int sl = tid + u * NZ;
       hk[u] = hkey[sl];
       hb[u] = 0ull;
-      if (hk[u] && EXPT != 4)
+      if (hk[u])
         hb[u] = atomicAdd(reinterpret_cast<unsigned long long *>(cnt) + (hk[u] - 1), hcnt[sl]);
     }
 #pragma unroll
@@ -239,9 +234,8 @@ k_zbin_direct(Geo g, PosPar pp, SphPar sp, TilePar tp, int log2n, const C2<T> *_
       ovf[1] = seg;
     } else {
       const int t = key[m] / kOct;
-      long long dst = (long long)t * tp.cap + (long long)(key[m] - t * kOct) * seg + rank;
-      if (EXPT == 3) dst = p[m];
-      if (EXPT != 2) rec_store<T>(srec, dst, x[m], y[m], z[m], (int)p[m] | flag[m]);
+      const long long dst = (long long)t * tp.cap + (long long)(key[m] - t * kOct) * seg + rank;
+      rec_store<T>(srec, dst, x[m], y[m], z[m], (int)p[m] | flag[m]);
     }
   }
 }

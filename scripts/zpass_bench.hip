@@ -1,6 +1,9 @@
-// scripts/zpass_bench.hip -- bench + check of the two kernels that would replace rocFFT's 2-D C2R in front of the
-// binning: k_ypass (in-place inverse complex FFT along y of planes-space arrays) and, later, the z pass fused into the
-// binning.  Correctness against a host DFT on sampled columns.
+// scripts/zpass_bench.hip -- check + bench of the two kernels that replace rocFFT's 2-D C2R in front of the binning
+// (barcode_amd/csrc/zpass.hpp): k_ypass against a host DFT on sampled columns; k_zbin_direct's displacements against the
+// field its input was made from and its counters against k_bin_direct's; their times, and what the no-op fallback
+// launches cost.  (The timing experiments that shaped k_zbin_direct -- without the transform, the record stores, the
+// counter atomics, with one counter per two / four octants, decorrelated workgroup order -- are recorded in
+// profiles/r03_zpass_bench.txt; their switches are no longer in the kernel.)
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -munsafe-fp-atomics -I barcode_amd/csrc scripts/zpass_bench.hip -o scripts/zpass_bench
 #include <cmath>
 #include <complex>
@@ -196,6 +199,20 @@ int main(int argc, char **argv) {
     CK(hipMemsetAsync(d_cnt, 0, (size_t)tp.ntiles * 8 * 4));
     CK(hipMemsetAsync(d_ovf, 0, 64));
   };
+  CK(hipMemset(d_ovf, 0, 64));
+  time_it("no-op: k_zbin_direct<PSI_ONLY>, 16384 workgroups", [&] {
+    k_zbin_direct<double, 256, true><<<(n / 2) * (n / 2), 256, ldsz>>>(g, pp, sp, tp, log2n, d_tw, d_c, d_cnt, d_ovf, nullptr, nullptr,
+                                                                    nullptr, nullptr, nullptr, d_psi2);
+  }, 0);
+  time_it("no-op: k_bin<double> fallback pass, 4096 workgroups", [&] {
+    k_bin<double><<<4096, 256>>>(g, pp, sp, tp, (int)(N / 256), d_psi, d_cnt, d_ovf, nullptr, d_V);
+  }, 0);
+  time_it("no-op: k_bin<double> fallback pass, 1024 workgroups", [&] {
+    k_bin<double><<<1024, 256>>>(g, pp, sp, tp, (int)(N / 256), d_psi, d_cnt, d_ovf, nullptr, d_V);
+  }, 0);
+  time_it("no-op: k_bin<double> fallback pass, 256 workgroups", [&] {
+    k_bin<double><<<256, 256>>>(g, pp, sp, tp, (int)(N / 256), d_psi, d_cnt, d_ovf, nullptr, d_V);
+  }, 0);
   for (int rep = 0; rep < 2; rep++) {
     time_it("k_bin_direct<double> (reads psi)", [&] {
       clear();
@@ -206,18 +223,6 @@ int main(int argc, char **argv) {
       k_zbin_direct<double, 256><<<(n / 2) * (n / 2), 256, ldsz>>>(g, pp, sp, tp, log2n, d_tw, d_c, d_cnt, d_ovf, d_rec, d_V,
                                                              d_zero, d_rho, nullptr, nullptr);
     }, 0);
-#define ZEX(E, what)                                                                                                  \
-  time_it(what, [&] {                                                                                                 \
-    clear();                                                                                                          \
-    k_zbin_direct<double, 256, false, E><<<(n / 2) * (n / 2), 256, ldsz>>>(g, pp, sp, tp, log2n, d_tw, d_c, d_cnt, d_ovf, d_rec, d_V, \
-                                                              d_zero, d_rho, nullptr, nullptr);                        \
-  }, 0)
-    ZEX(1, "  without the LDS transform");
-    ZEX(2, "  without the record stores");
-    ZEX(3, "  records at the Lagrangian index");
-    ZEX(4, "  without the global counter atomics");
-    ZEX(8, "  columns 17 apart in j in consecutive workgroups");
-    ZEX(9, "  ... and 17 apart in i in consecutive rows of workgroups");
     time_it("k_zbin_direct<double> + psi stored", [&] {
       clear();
       k_zbin_direct<double, 256><<<(n / 2) * (n / 2), 256, ldsz>>>(g, pp, sp, tp, log2n, d_tw, d_c, d_cnt, d_ovf, d_rec, d_V,
