@@ -1,6 +1,10 @@
 // zpass.hpp -- The last two passes of the planes-mode inverse transform done by the engine itself, so that the z pass
 // can end in the binning instead of in HBM: k_ypass (inverse complex FFTs along y, in place) and k_zbin_direct (inverse
 // real FFTs along z of the three displacement components, particle positions, one-pass binning).
+// Reference work these two kernels cover: the last two of the three passes of each of theta2vel's inverse transforms
+// (EqSolvers.cc:274-276 -> fftC2Rplanned, fftwrapper.cc:88-102; the x pass is in k_step_boundary_x), and everything
+// k_bin_direct covers (disp_part.cc:55-126, pacman.cpp:20-28, rsd.cc:28-68 + the tile binning, which has no counterpart
+// upstream).  Same numbers as the rocFFT path to transform round-off (tests/test_gpu_large.py::*z_pass_inside_the_binning*).
 // Part of the bchmc engine's kernel set; include through kernels.hpp (after step_boundary_x.hpp and tiles.hpp).
 #pragma once
 #include "common.hpp"
