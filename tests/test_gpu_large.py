@@ -276,6 +276,32 @@ def test_256_z_pass_inside_the_binning_alpt_and_deterministic(big, monkeypatch):
         assert rel_l2(outs[1][0], outs[0][0]) < 1e-13 and rel_l2(outs[1][1], outs[0][1]) < 1e-11
 
 
+def test_256_runaway_guard_with_the_fused_z_pass(big, monkeypatch):
+    """HMC.cc:360-364 at the benchmark size: a momentum of 1e60 trips the guard after the first step; the steps that were
+    already enqueued run their y / z passes and the binning on whatever the stopped boundary kernels left in Ck (huge or
+    non-finite displacements: positions are folded into the box or dropped, never used as indices) and must leave the
+    returned state alone -- the same state as on the rocFFT path, and a normal trajectory afterwards is unaffected."""
+    from barcode_amd.engine import Engine
+    p, f, _, dX = big
+    window, noise, nobs = inputs.mock_observations(p, dX)
+    eps = 0.5 * p.eps_heuristic()
+    p_bad = f["p0"].copy().ravel()
+    p_bad[0] = 1e60
+    outs = []
+    for nozbin in ("1", "0"):
+        monkeypatch.setenv("BCHMC_NO_ZBIN", nozbin)
+        e2 = Engine(p)
+        e2.upload(signal_PS=f["signal_PS"], mass_f=f["mass_f"], window=window, noise=noise, nobs=nobs)
+        qb, pb, doneb = e2.leapfrog(f["q0"], p_bad, 1e-6, 6)
+        q1, p1, done = e2.leapfrog(f["q0"], f["p0"], eps, 4)
+        assert doneb == 1 and done == 4
+        assert np.all(np.isfinite(qb)) and np.all(np.isfinite(q1))
+        outs.append((qb, pb, q1, p1))
+        e2.close()
+    for a, b in zip(outs[0], outs[1]):
+        assert rel_l2(b, a) < 1e-12
+
+
 def test_256_energy_terms_against_real_space_evaluation(big):
     """The engine evaluates 1/2 x^T A x by Parseval in k-space; compare with the reference's real-space form
     0.5 * sum(x * IFFT[w FFT x]) (HMC.cc:101-115, gaussian.cpp:24-32) computed with numpy, and the Gaussian
