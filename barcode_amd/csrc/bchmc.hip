@@ -895,6 +895,14 @@ struct Pipe {
            !env_on("BCHMC_NO_ZBIN");  // (mk 3 + calc_h 2 on tiles: nothing but the fallback sort reads Psi after the binning)
   }
 
+  // the engine's own row + column passes of the planes-mode R2C: where rocFFT's column kernel is the slower one (n = 512)
+  static bool yfwd_ok(const bchmc_handle *h) {
+    // fp32 fields: R2C class 2.59 -> 1.85 ms per step (17.96 -> 17.35 ms, +3.5 %); fp64: rocFFT's double-precision
+    // column kernel is as fast as the pair (3.14 against 3.16 ms) and stays unless BCHMC_YFWD_F64=1
+    return h->g.n == 512 && (sizeof(T) == 4 || env_on("BCHMC_YFWD_F64")) && h->planes_ok && h->xtw &&
+           !env_on("BCHMC_NO_YFWD");
+  }
+
   // C2R of the three displacement components, mass assignment, sum of rho.  Lag2Eul.cc:90-131 / 363-423.
   // defer_combine: the caller (like_force) sums the staged density images itself, fused with the likelihood partial
   static int forward_rest(bchmc_handle *h, int rsd, bool defer_combine = false) {
@@ -1224,7 +1232,26 @@ struct Pipe {
       }
       HIPCHK(hipGetLastError());
     }
-    CHK(fft_exec(h, h->planes_r2c ? h->r2c2d : h->r2c3, h->V, h->Ck, BCHMC_K_FFT_R2C));
+    if (h->planes_r2c && yfwd_ok(h)) {
+      // 512^3: the engine's own row and column passes (rocFFT's length-512 column kernel runs at 2.3 TB/s, its 1-D row
+      // plan alone at half the speed of the same pass inside the 2-D plan: k_zr2c + k_ypass<forward>, zpass.hpp)
+      ProfScope ps(h, BCHMC_K_FFT_R2C);
+      constexpr int KB = 128 / (int)sizeof(CT);
+      const int n = h->g.n;
+      const CT *tw = reinterpret_cast<const CT *>(h->xtw);
+      const size_t zl = ((size_t)n * 6 + n / 2) * sizeof(CT), yl = ((size_t)n * KB + n / 2) * sizeof(CT);
+      auto kz = k_zr2c<T, 512>;
+      auto ky = k_ypass<T, 512, 512 * KB / 512, BCHMC_YPASS_NT, false>;
+      if (zl > 48 * 1024)
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kz), hipFuncAttributeMaxDynamicSharedMemorySize, (int)zl));
+      if (yl > 48 * 1024)
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(ky), hipFuncAttributeMaxDynamicSharedMemorySize, (int)yl));
+      kz<<<(n / 2) * (n / 2), 512, zl, h->stream>>>(h->g, h->log2n, tw, R(h->V), C(h->Ck));
+      ky<<<3 * n * (h->g.nhp / KB), 512, yl, h->stream>>>(h->g, h->log2n, tw, C(h->Ck));
+      HIPCHK(hipGetLastError());
+    } else {
+      CHK(fft_exec(h, h->planes_r2c ? h->r2c2d : h->r2c3, h->V, h->Ck, BCHMC_K_FFT_R2C));
+    }
     *like_mode = 0;
     return BCHMC_OK;
   }

@@ -26,7 +26,9 @@ namespace bchmc {
 // alone (its batch is one-dimensional; the y columns are batched over i AND k).  Unnormalised, like rocFFT.
 // Requires n a power of two with n == PER * NT / KB and nhp a multiple of KB.
 // ======================================================================================================
-template <typename T, int NT, int PER, int HINT = 0>  // streaming hints: 1 loads and stores, 2 loads only, 3 stores only
+// INV = false: the forward transform (the y pass of the planes-mode R2C after rocFFT's row pass, used where rocFFT's own
+// column kernel is the slower one: 512^3).
+template <typename T, int NT, int PER, int HINT = 0, bool INV = true>  // streaming hints: 1 loads and stores, 2 loads only, 3 stores only
 __global__ void __launch_bounds__(NT)
 k_ypass(Geo g, int log2n, const C2<T> *__restrict__ twiddle, C2<T> *c) {
   constexpr int KB = 128 / (int)sizeof(C2<T>);
@@ -51,7 +53,7 @@ k_ypass(Geo g, int log2n, const C2<T> *__restrict__ twiddle, C2<T> *c) {
 #pragma unroll
   for (int m = 0; m < PER; m++) s[(int)(__brev((unsigned)(jrow + rows * m)) >> shift) * KB + col] = v[m];
   __syncthreads();
-  xfft_inplace<T>(s, tw, n, log2n, KB, true);
+  xfft_inplace<T>(s, tw, n, log2n, KB, INV);
 #pragma unroll
   for (int m = 0; m < PER; m++) {
     const int j = jrow + rows * m;
@@ -240,6 +242,69 @@ k_zbin_direct(Geo g, PosPar pp, SphPar sp, TilePar tp, int log2n, const C2<T> *_
       const int t = key[m] / kOct;
       const long long dst = (long long)t * tp.cap + (long long)(key[m] - t * kOct) * seg + rank;
       rec_store<T>(srec, dst, x[m], y[m], z[m], (int)p[m] | flag[m]);
+    }
+  }
+}
+
+// ======================================================================================================
+// k_zr2c: the row pass of the planes-mode R2C (unnormalised forward real transforms along z of the three components
+// of V), the mirror image of k_zbin_direct's transform part -- used where rocFFT's 2-D R2C is the slower pair
+// (512^3: its length-512 column kernel runs at 2.3 TB/s; k_zr2c + k_ypass<forward> at 5+).  One workgroup of n
+// threads per 2 x 2 x n column: thread t packs the rows (i0 + f, j0) and (i0 + f, j0 + 1) at z = t as a + i b into the
+// six interleaved columns of the LDS tile, one radix-4 call, and the half-complex spectra come out of
+//   A[k] = (Z[k] + conj(Z[n - k])) / 2,   B[k] = (Z[k] - conj(Z[n - k])) / (2 i),   k = 0 .. n / 2.
+// Output layout: element (i, j, k) at k + nhp (j + n i) of each component, like rocFFT's row pass inside the 2-D plan;
+// the row padding k > n / 2 is left as it is (columns of the later passes are independent, reductions skip it).
+// Replaces the z part of fftR2Cplanned (fftwrapper.cc:104-119) for HMC_models.cc:342-349's three transforms of V.
+// ======================================================================================================
+template <typename T, int NZ>
+__global__ void __launch_bounds__(NZ)
+k_zr2c(Geo g, int log2n, const C2<T> *__restrict__ twiddle, const T *__restrict__ V, C2<T> *__restrict__ ck) {
+  constexpr int KF = 6;
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw_zr[];
+  const int n = g.n, tid = (int)threadIdx.x;
+  C2<T> *s = reinterpret_cast<C2<T> *>(s_raw_zr);  // n * KF
+  C2<T> *tw = s + (size_t)n * KF;                 // n / 2
+  for (int t = tid; t < n / 2; t += NZ) tw[t] = twiddle[t];
+  const int nb = n >> 1;
+  const int j0 = 2 * ((int)blockIdx.x % nb), i0 = 2 * ((int)blockIdx.x / nb);
+  const int shift = 32 - log2n;
+  {
+    const int r = (int)(__brev((unsigned)tid) >> shift) * KF;
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+      for (int f = 0; f < 2; f++) {
+        const long long p = tid + (long long)n * (j0 + (long long)n * (i0 + f));  // lattice site (i0 + f, j0, t)
+        C2<T> v;
+        v.x = V[(long long)c * g.N + p];
+        v.y = V[(long long)c * g.N + p + n];  // (i0 + f, j0 + 1, t)
+        s[r + 2 * c + f] = v;
+      }
+  }
+  __syncthreads();
+  xfft_inplace<T>(s, tw, n, log2n, KF, false);
+  // wave w: pair f = w & 1, wavenumbers kk = 64 (w >> 1) + lane < n / 2; the threads with kk == 0 also store k = n / 2
+  const int w = tid >> 6, f = w & 1, kk = ((w >> 1) << 6) + (tid & 63);
+  const long long row = (long long)g.nhp * (j0 + (long long)n * (i0 + f));
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    const int colf = 2 * c + f;
+    const C2<T> zk = s[kk * KF + colf], zm = s[((n - kk) & (n - 1)) * KF + colf];
+    C2<T> a, b;
+    a.x = T(0.5) * (zk.x + zm.x);
+    a.y = T(0.5) * (zk.y - zm.y);
+    b.x = T(0.5) * (zk.y + zm.y);
+    b.y = T(-0.5) * (zk.x - zm.x);
+    ck[(long long)c * g.Nhp + row + kk] = a;
+    ck[(long long)c * g.Nhp + row + g.nhp + kk] = b;
+    if (kk == 0) {
+      const C2<T> zh = s[(n / 2) * KF + colf];
+      C2<T> ah, bh;
+      ah.x = zh.x; ah.y = T(0);
+      bh.x = zh.y; bh.y = T(0);
+      ck[(long long)c * g.Nhp + row + n / 2] = ah;
+      ck[(long long)c * g.Nhp + row + g.nhp + n / 2] = bh;
     }
   }
 }
