@@ -18,33 +18,38 @@
   } while (0)
 
 typedef double dv2 __attribute__((ext_vector_type(2)));
-constexpr int n = 256, nhp = 136, KB = 8;
-constexpr long long Nhp = (long long)n * n * nhp;
+typedef float fv2 __attribute__((ext_vector_type(2)));
 
-struct Arrs {
-  const dv2 *in[6];
-  dv2 *out[5];
+template <typename E> struct Arrs {
+  const E *in[6];
+  E *out[5];
+};
+struct Dim {
+  int n, nhp;
 };
 
-template <bool NT>
-__device__ __forceinline__ dv2 ld(const dv2 *p) { return NT ? __builtin_nontemporal_load(p) : *p; }
-template <bool NT>
-__device__ __forceinline__ void st(dv2 *p, dv2 v) {
+template <bool NT, typename E>
+__device__ __forceinline__ E ld(const E *p) { return NT ? __builtin_nontemporal_load(p) : *p; }
+template <bool NT, typename E>
+__device__ __forceinline__ void st(E *p, E v) {
   if (NT) __builtin_nontemporal_store(v, p);
   else *p = v;
 }
 
 // MODE 0: contiguous (workgroup b takes elements [b * 2048, (b + 1) * 2048)); 1: x-columns (j, k-block) x all i;
 // 2: y-columns (i, k-block) x all j.  512 threads, 4 elements per thread and array, like the boundary kernel.
-template <int MODE, bool NT, int NIN, int NOUT>
-__global__ void __launch_bounds__(512) k_copy(Arrs a) {
+// workgroup: NTH threads, PER elements per thread and array, KB = 128 B / sizeof(E) columns: n == PER * NTH / KB rows
+template <int MODE, bool NT, int NIN, int NOUT, typename E, int NTH, int PER>
+__global__ void __launch_bounds__(NTH) k_copy(Arrs<E> a, Dim d) {
+  constexpr int KB = 128 / (int)sizeof(E), ROWS = NTH / KB;
+  const int n = d.n, nhp = d.nhp;
   const int ntk = nhp / KB;
-  const int c = threadIdx.x % KB, row = threadIdx.x / KB;  // 64 rows of 8 columns
-  long long e[4];
+  const int c = threadIdx.x % KB, row = threadIdx.x / KB;
+  long long e[PER];
 #pragma unroll
-  for (int m = 0; m < 4; m++) {
-    const int r = row + 64 * m;
-    if (MODE == 0) e[m] = (long long)blockIdx.x * 2048 + threadIdx.x + 512 * m;
+  for (int m = 0; m < PER; m++) {
+    const int r = row + ROWS * m;
+    if (MODE == 0) e[m] = (long long)blockIdx.x * (NTH * PER) + threadIdx.x + NTH * m;
     if (MODE == 1) {
       const int j = blockIdx.x / ntk, k = (blockIdx.x % ntk) * KB + c;
       e[m] = k + (long long)nhp * (j + (long long)n * r);
@@ -54,33 +59,39 @@ __global__ void __launch_bounds__(512) k_copy(Arrs a) {
       e[m] = k + (long long)nhp * (r + (long long)n * i);
     }
   }
-  dv2 acc[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+  E acc[PER];
+#pragma unroll
+  for (int m = 0; m < PER; m++) acc[m] = E{0, 0};
 #pragma unroll
   for (int s = 0; s < NIN; s++)
 #pragma unroll
-    for (int m = 0; m < 4; m++) acc[m] += ld<NT>(a.in[s] + e[m]);
+    for (int m = 0; m < PER; m++) acc[m] += ld<NT>(a.in[s] + e[m]);
 #pragma unroll
   for (int s = 0; s < NOUT; s++)
 #pragma unroll
-    for (int m = 0; m < 4; m++) st<NT>(a.out[s] + e[m], acc[m]);
+    for (int m = 0; m < PER; m++) st<NT>(a.out[s] + e[m], acc[m]);
 }
 
-int main() {
-  Arrs a;
+template <typename E, int NTH, int PER>
+static void suite(const char *title, int n, int nhp) {
+  constexpr int KB = 128 / (int)sizeof(E);
+  const long long Nhp = (long long)n * n * nhp;
+  Arrs<E> a;
   for (int s = 0; s < 6; s++) {
-    dv2 *p;
-    CK(hipMalloc(&p, Nhp * 16));
-    CK(hipMemset(p, 0, Nhp * 16));
+    E *p;
+    CK(hipMalloc(&p, Nhp * sizeof(E)));
+    CK(hipMemset(p, 0, Nhp * sizeof(E)));
     a.in[s] = p;
   }
-  for (int s = 0; s < 5; s++) CK(hipMalloc(&a.out[s], Nhp * 16));
+  for (int s = 0; s < 5; s++) CK(hipMalloc(&a.out[s], Nhp * sizeof(E)));
+  const Dim d{n, nhp};
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
-  const int grid = n * (nhp / KB);  // 4352 workgroups of 2048 elements = Nhp
+  const int grid = n * (nhp / KB);  // workgroups of n * KB elements
   auto run = [&](const char *name, auto launch, double bytes) {
     float best = 1e9f;
-    for (int r = 0; r < 12; r++) {
+    for (int r = 0; r < 10; r++) {
       CK(hipEventRecord(e0));
       launch();
       CK(hipEventRecord(e1));
@@ -89,22 +100,28 @@ int main() {
       CK(hipEventElapsedTime(&ms, e0, e1));
       if (r >= 2) best = std::min(best, ms);
     }
-    printf("%-44s %.4f ms  %.2f TB/s\n", name, best, bytes / best * 1e-9);
+    printf("  %-42s %.4f ms  %.2f TB/s\n", name, best, bytes / best * 1e-9);
     fflush(stdout);
   };
-  const double B11 = 11.0 * Nhp * 16, B2 = 2.0 * Nhp * 16, B6 = 6.0 * Nhp * 16, B5 = 5.0 * Nhp * 16;
-  run("contiguous, 6 in + 5 out", [&] { k_copy<0, false, 6, 5><<<grid, 512>>>(a); }, B11);
-  run("contiguous, 6 in + 5 out, nt", [&] { k_copy<0, true, 6, 5><<<grid, 512>>>(a); }, B11);
-  run("x-columns, 6 in + 5 out", [&] { k_copy<1, false, 6, 5><<<grid, 512>>>(a); }, B11);
-  run("x-columns, 6 in + 5 out, nt", [&] { k_copy<1, true, 6, 5><<<grid, 512>>>(a); }, B11);
-  run("y-columns, 6 in + 5 out", [&] { k_copy<2, false, 6, 5><<<grid, 512>>>(a); }, B11);
-  run("y-columns, 6 in + 5 out, nt", [&] { k_copy<2, true, 6, 5><<<grid, 512>>>(a); }, B11);
-  run("x-columns, 6 in only (1 out)", [&] { k_copy<1, true, 6, 1><<<grid, 512>>>(a); }, B6 + B2 / 2);
-  run("x-columns, 1 in + 5 out", [&] { k_copy<1, true, 1, 5><<<grid, 512>>>(a); }, B5 + B2 / 2);
-  run("contiguous, 6 in only (1 out)", [&] { k_copy<0, true, 6, 1><<<grid, 512>>>(a); }, B6 + B2 / 2);
-  run("contiguous, 1 in + 5 out", [&] { k_copy<0, true, 1, 5><<<grid, 512>>>(a); }, B5 + B2 / 2);
-  run("x-columns, 1 in + 1 out", [&] { k_copy<1, true, 1, 1><<<grid, 512>>>(a); }, B2);
-  run("y-columns, 1 in + 1 out", [&] { k_copy<2, true, 1, 1><<<grid, 512>>>(a); }, B2);
-  run("contiguous, 1 in + 1 out", [&] { k_copy<0, true, 1, 1><<<grid, 512>>>(a); }, B2);
+  printf("%s\n", title);
+  const double B = (double)Nhp * sizeof(E);
+  run("contiguous, 6 in + 5 out, nt", [&] { k_copy<0, true, 6, 5, E, NTH, PER><<<grid, NTH>>>(a, d); }, 11 * B);
+  run("x-columns, 6 in + 5 out", [&] { k_copy<1, false, 6, 5, E, NTH, PER><<<grid, NTH>>>(a, d); }, 11 * B);
+  run("x-columns, 6 in + 5 out, nt", [&] { k_copy<1, true, 6, 5, E, NTH, PER><<<grid, NTH>>>(a, d); }, 11 * B);
+  run("y-columns, 6 in + 5 out, nt", [&] { k_copy<2, true, 6, 5, E, NTH, PER><<<grid, NTH>>>(a, d); }, 11 * B);
+  run("x-columns, 6 in only (1 out)", [&] { k_copy<1, true, 6, 1, E, NTH, PER><<<grid, NTH>>>(a, d); }, 7 * B);
+  run("x-columns, 1 in + 5 out", [&] { k_copy<1, true, 1, 5, E, NTH, PER><<<grid, NTH>>>(a, d); }, 6 * B);
+  run("x-columns, 1 in + 1 out", [&] { k_copy<1, true, 1, 1, E, NTH, PER><<<grid, NTH>>>(a, d); }, 2 * B);
+  run("y-columns, 1 in + 1 out", [&] { k_copy<2, true, 1, 1, E, NTH, PER><<<grid, NTH>>>(a, d); }, 2 * B);
+  run("contiguous, 1 in + 1 out", [&] { k_copy<0, true, 1, 1, E, NTH, PER><<<grid, NTH>>>(a, d); }, 2 * B);
+  for (int s = 0; s < 6; s++) CK(hipFree((void *)a.in[s]));
+  for (int s = 0; s < 5; s++) CK(hipFree(a.out[s]));
+}
+
+int main() {
+  suite<dv2, 512, 4>("256^3 fp64 (rows of 136 complex), 512 threads x 4", 256, 136);
+  suite<fv2, 1024, 8>("512^3 fp32 (rows of 272 complex), 1024 threads x 8", 512, 272);
+  suite<fv2, 512, 16>("512^3 fp32, 512 threads x 16", 512, 272);
+  suite<dv2, 512, 8>("512^3 fp64 (rows of 264 complex), 512 threads x 8", 512, 264);
   return 0;
 }
